@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures under tests/golden/ by running the *reference* implementation on CPU.
+
+Runs only in the build container (the reference at /root/reference never travels to the GPU box).
+The reference's `models` package is imported unmodified; the one harness-side shim is
+`torch.Optional = typing.Optional` (its annotations at models/var.py:241-242 need torch<=2.1 otherwise).
+
+Weights come from var_amd.detinit (hash of seed/name/index), loaded through the reference's own
+`load_state_dict(strict=True)`, so (a) the GPU box can rebuild the identical weights without the
+reference and (b) a key/shape mismatch between detinit and the reference fails here.
+
+What is recorded per end-to-end case (reference call chain: models/var.py:126-190):
+  idx        (B, L) int32      token ids the reference sampled at every scale (helpers.py:6-19)
+  img        (B,3,H,W) f32     final decoded image in [0,1] (var.py:190, vqvae.py:62-63)
+  f_hat_s{si}(B,Cvae,P,P) f32  accumulated feature map after scale si (quant.py:187-196)
+  pool_s{si} (B,Cvae,p',p')    area-pooled input of the next scale (quant.py:192)
+  logits_s{si}                 raw 2B-row logits before CFG (var.py:170): all rows for `full_logits`
+                               cases, else rows t in {0, l-1}
+  lsum/labs  (S,) f64          sum / abs-sum of each scale's raw logits (checksum for the big cases)
+  noise_head (S,8) f32, noise_sum (S,) f64   head/checksum of the Exp(1) fill torch.multinomial draws
+                               (one (B*l,V) fill per scale), so tests can regenerate it with a CPU
+                               torch.Generator and prove they got the same stream.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import typing
+
+import numpy as np
+import torch
+
+torch.Optional = typing.Optional          # shim, see module docstring
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, '/root/reference')
+sys.path.insert(1, REPO)
+
+from models import build_vae_var            # noqa: E402  (the REFERENCE package)
+from var_amd.detinit import fill_module_    # noqa: E402
+
+GOLD = os.path.join(REPO, 'tests', 'golden')
+
+CASES = {
+    # name: dict(depth, ch, patch_nums, attn_l2_norm, shared_aln, B, labels, seed, cfg, top_k, top_p, full_logits)
+    't_pn123_base':  dict(depth=2, ch=32, patch_nums=(1, 2, 3), attn_l2_norm=True, shared_aln=False, labels=(3, 7), seed=0, cfg=1.5, top_k=900, top_p=0.96, full_logits=True),
+    't_pn12345':     dict(depth=2, ch=32, patch_nums=(1, 2, 3, 4, 5), attn_l2_norm=True, shared_aln=False, labels=(980, 437), seed=1, cfg=1.5, top_k=900, top_p=0.96, full_logits=False),
+    't_nol2':        dict(depth=2, ch=32, patch_nums=(1, 2, 3), attn_l2_norm=False, shared_aln=False, labels=(22, 562), seed=2, cfg=1.5, top_k=900, top_p=0.96, full_logits=True),
+    't_saln':        dict(depth=2, ch=32, patch_nums=(1, 2, 3), attn_l2_norm=True, shared_aln=True, labels=(1, 999), seed=3, cfg=1.5, top_k=900, top_p=0.96, full_logits=True),
+    't_greedy':      dict(depth=2, ch=32, patch_nums=(1, 2, 3), attn_l2_norm=True, shared_aln=False, labels=(5, 6), seed=4, cfg=4.0, top_k=1, top_p=0.0, full_logits=False),
+    't_nofilter':    dict(depth=2, ch=32, patch_nums=(1, 2, 3), attn_l2_norm=True, shared_aln=False, labels=(100, 200), seed=5, cfg=0.0, top_k=0, top_p=0.0, full_logits=False),
+    't_b3_pn1234':   dict(depth=2, ch=32, patch_nums=(1, 2, 3, 4), attn_l2_norm=True, shared_aln=False, labels=(0, 500, 999), seed=123, cfg=3.0, top_k=600, top_p=0.5, full_logits=False),
+    'd16_pn123':     dict(depth=16, ch=160, patch_nums=(1, 2, 3), attn_l2_norm=True, shared_aln=False, labels=(3, 7), seed=0, cfg=1.5, top_k=900, top_p=0.96, full_logits=False),
+    'd16_full':      dict(depth=16, ch=160, patch_nums=(1, 2, 3, 4, 5, 6, 8, 10, 13, 16), attn_l2_norm=True, shared_aln=False, labels=(0, 7), seed=0, cfg=1.5, top_k=900, top_p=0.96, full_logits=False),
+}
+
+
+def build_reference(cfg, init_seed=0):
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        vae, var = build_vae_var(device='cpu', patch_nums=tuple(cfg['patch_nums']), depth=cfg['depth'], ch=cfg['ch'],
+                                 shared_aln=cfg['shared_aln'], attn_l2_norm=cfg['attn_l2_norm'])
+    fill_module_(var, cfg['depth'], init_seed, 'var.')
+    fill_module_(vae, cfg['depth'], init_seed, 'vae.')
+    # round-trip through the reference's strict loader: proves key/shape compatibility of detinit
+    var.load_state_dict({k: v.clone() for k, v in var.state_dict().items()}, strict=True)
+    vae.load_state_dict({k: v.clone() for k, v in vae.state_dict().items()}, strict=True)
+    return vae.eval(), var.eval()
+
+
+def run_case(name, cfg):
+    vae, var = build_reference(cfg)
+    pns = tuple(cfg['patch_nums'])
+    B = len(cfg['labels'])
+    rec = {}
+    logits, idxs, fhats, pools = [], [], [], []
+
+    orig_get_logits = var.get_logits
+    def get_logits(h, c):
+        r = orig_get_logits(h, c)
+        logits.append(r.detach().clone())
+        return r
+    var.get_logits = get_logits
+
+    quant = vae.quantize
+    hk = quant.embedding.register_forward_hook(lambda m, inp, out: idxs.append(inp[0].detach().clone()))
+    orig_next = quant.get_next_autoregressive_input
+    def get_next(si, SN, f_hat, h):
+        f, nxt = orig_next(si, SN, f_hat, h)
+        fhats.append(f.detach().clone())
+        pools.append(nxt.detach().clone())
+        return f, nxt
+    quant.get_next_autoregressive_input = get_next
+
+    t0 = time.time()
+    with torch.inference_mode():
+        img = var.autoregressive_infer_cfg(B, torch.tensor(cfg['labels'], dtype=torch.long), g_seed=cfg['seed'], cfg=cfg['cfg'],
+                                           top_k=cfg['top_k'], top_p=cfg['top_p'], more_smooth=False)
+    dt = time.time() - t0
+    hk.remove()
+
+    rec['img'] = img.numpy().astype(np.float32)
+    rec['idx'] = torch.cat(idxs, dim=1).numpy().astype(np.int32)
+    lsum, labs = [], []
+    for si, pn in enumerate(pns):
+        lg = logits[si].numpy()
+        lsum.append(lg.astype(np.float64).sum()); labs.append(np.abs(lg.astype(np.float64)).sum())
+        rec[f'logits_s{si}'] = lg if cfg['full_logits'] else lg[:, sorted({0, pn * pn - 1}), :]
+        rec[f'f_hat_s{si}'] = fhats[si].numpy().copy()
+        if si < len(pns) - 1:
+            rec[f'pool_s{si}'] = pools[si].numpy().copy()
+    rec['lsum'] = np.array(lsum); rec['labs'] = np.array(labs)
+    # the Exp(1) noise stream the reference consumed (torch.multinomial, n=1: one exponential_ fill per scale)
+    g = torch.Generator(device='cpu'); g.manual_seed(cfg['seed'])
+    V = logits[0].shape[-1]
+    nh, ns = [], []
+    for pn in pns:
+        q = torch.empty(B * pn * pn, V, dtype=torch.float32).exponential_(1, generator=g)
+        nh.append(q.view(-1)[:8].numpy().copy()); ns.append(q.double().sum().item())
+    rec['noise_head'] = np.stack(nh); rec['noise_sum'] = np.array(ns)
+    meta = dict(cfg); meta['B'] = B; meta['V'] = int(V); meta['ref_seconds'] = dt; meta['torch'] = torch.__version__
+    meta['threads'] = torch.get_num_threads()
+    rec['meta'] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(GOLD, f'e2e_{name}.npz'), **rec)
+    print(f'[gen_golden] {name}: {dt:.2f}s  img mean {img.mean():.4f}  tokens {rec["idx"].shape}', flush=True)
+
+
+def run_nearest_code():
+    """A17 fixture: VectorQuantizer2.f_to_idxBl_or_fhat (reference models/quant.py:135-166) on a random feature map."""
+    cfg = CASES['t_pn12345']
+    vae, _ = build_reference(cfg)
+    P = cfg['patch_nums'][-1]
+    g = torch.Generator(); g.manual_seed(77)
+    f = torch.randn(3, 32, P, P, generator=g) * 1.5
+    with torch.inference_mode():
+        idx = vae.quantize.f_to_idxBl_or_fhat(f, to_fhat=False)
+        fh = vae.quantize.f_to_idxBl_or_fhat(f, to_fhat=True)
+        var_in = vae.quantize.idxBl_to_var_input(idx)
+    rec = dict(f=f.numpy(), var_input=var_in.numpy(), meta=np.array(json.dumps(dict(cfg))))
+    for si, (i, h) in enumerate(zip(idx, fh)):
+        rec[f'idx_s{si}'] = i.numpy().astype(np.int32); rec[f'f_hat_s{si}'] = h.numpy()
+    np.savez_compressed(os.path.join(GOLD, 'nearest_code.npz'), **rec)
+    print('[gen_golden] nearest_code done', flush=True)
+
+
+def run_sampler_vectors():
+    """A8 fixture: sample_with_top_k_top_p_ (reference models/helpers.py:6-19) on synthetic logits incl. ties and edge settings."""
+    from models.helpers import sample_with_top_k_top_p_
+    g = torch.Generator(); g.manual_seed(2024)
+    rec = {}
+    cases = []
+    for ci, (B, l, V, top_k, top_p, kind) in enumerate([
+        (2, 5, 4096, 900, 0.96, 'normal'), (2, 5, 4096, 0, 0.0, 'normal'), (2, 5, 4096, 1, 0.0, 'normal'),
+        (2, 5, 4096, 0, 0.5, 'normal'), (2, 5, 4096, 50, 0.999, 'peaked'), (2, 5, 4096, 900, 0.96, 'ties'),
+        (1, 3, 4096, 4096, 0.0001, 'normal'), (2, 4, 512, 100, 0.9, 'normal'),
+    ]):
+        if kind == 'normal': lg = torch.randn(B, l, V, generator=g) * 2.5
+        elif kind == 'peaked': lg = torch.randn(B, l, V, generator=g) * 8.0
+        else: lg = (torch.randn(B, l, V, generator=g) * 2.0).round()       # many exact ties
+        gs = torch.Generator(); gs.manual_seed(1000 + ci)
+        noise = torch.empty(B * l, V).exponential_(1, generator=torch.Generator().manual_seed(1000 + ci))
+        work = lg.clone()
+        idx = sample_with_top_k_top_p_(work, rng=gs, top_k=top_k, top_p=top_p, num_samples=1)[:, :, 0]
+        rec[f'logits_{ci}'] = lg.numpy(); rec[f'noise_{ci}'] = noise.numpy(); rec[f'idx_{ci}'] = idx.numpy().astype(np.int32)
+        rec[f'kept_{ci}'] = torch.isfinite(work).numpy()
+        cases.append(dict(B=B, l=l, V=V, top_k=top_k, top_p=top_p, kind=kind))
+    rec['meta'] = np.array(json.dumps(cases))
+    np.savez_compressed(os.path.join(GOLD, 'sampler.npz'), **rec)
+    print('[gen_golden] sampler done', flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--only', nargs='*', default=None)
+    args = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    torch.manual_seed(0)
+    for name, cfg in CASES.items():
+        if args.only and name not in args.only: continue
+        run_case(name, cfg)
+    if not args.only or 'nearest_code' in args.only: run_nearest_code()
+    if not args.only or 'sampler' in args.only: run_sampler_vectors()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,123 @@
+"""Deterministic, machine-independent weight initialisation for parity fixtures and the bench.
+
+There are no pretrained checkpoints on either box (no network), and the reference's own random init
+leaves the VQVAE convolutions as uninitialised memory (reference models/__init__.py:24-25 no-ops
+``reset_parameters``; VAR.init_weights, models/var.py:577-627, never visits the VAE).  So every
+random-init run here fills *all* parameters from an integer hash of (seed, parameter name, element
+index): the same state-dict can be regenerated bit-for-bit on the GPU box without shipping tensors.
+
+The magnitudes are "hot" on purpose: with the reference's default init the
+AdaLN gammas are 1e-5 and the logits are ~uniform, which would make parity tests insensitive to
+errors inside the blocks.  Here every residual branch, bias and modulation term carries weight.
+"""
+from __future__ import annotations
+
+import math
+import re
+import zlib
+from typing import Dict, Mapping, Tuple
+
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    """Vectorised splitmix64 finaliser on uint64 (wrap-around arithmetic)."""
+    with np.errstate(over='ignore'):
+        x = (x + np.uint64(0x9E3779B97F4A7C15)) & _M64
+        x = ((x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+        x = ((x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+        x = x ^ (x >> np.uint64(31))
+    return x
+
+
+def hash_uniform(name: str, numel: int, seed: int = 0) -> np.ndarray:
+    """`numel` float32 values in [-1, 1), exact multiples of 2^-23, a pure function of (seed, name, index)."""
+    key = (np.uint64(zlib.crc32(name.encode())) << np.uint64(32)) ^ np.uint64(seed & 0xFFFFFFFF) ^ (np.uint64(len(name)) << np.uint64(56))
+    key = _splitmix64(np.array([key], dtype=np.uint64))[0]   # decorrelate the per-tensor streams
+    out = np.empty(numel, dtype=np.float32)
+    step = 1 << 24
+    for s in range(0, numel, step):
+        e = min(numel, s + step)
+        ctr = np.arange(s, e, dtype=np.uint64)
+        h = _splitmix64(ctr ^ key)
+        u24 = (h >> np.uint64(40)).astype(np.int64)           # top 24 bits
+        out[s:e] = (u24 - (1 << 23)).astype(np.float32) * np.float32(2.0 ** -23)
+    return out
+
+
+def _rule(name: str, shape: Tuple[int, ...], depth: int) -> Tuple[float, float]:
+    """(amplitude, offset): value = offset + amplitude * U[-1,1).  Returns (0,0) for 'keep as is'."""
+    last = name.split('.')[-1]
+    fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else 1
+    # ---- VAR transformer -------------------------------------------------------------------------------------
+    if name in ('pos_start', 'pos_1LC') or name == 'lvl_embed.weight':
+        return 0.5, 0.0
+    if name == 'class_emb.weight':
+        return 1.0, 0.0
+    if name.startswith('word_embed.'):
+        return (math.sqrt(3.0 / fan_in), 0.0) if last == 'weight' else (0.1, 0.0)
+    if name.endswith('scale_mul_1H11'):
+        return 0.5, math.log(4.0)
+    if name.endswith('q_bias') or name.endswith('v_bias'):
+        return 0.1, 0.0
+    if name.endswith('ada_gss'):
+        return 0.3, 0.35
+    if re.search(r'(ada_lin\.1|shared_ada_lin\.1)\.weight$', name):
+        return 0.6 * math.sqrt(3.0 / fan_in), 0.0
+    if re.search(r'(ada_lin\.1|shared_ada_lin\.1)\.bias$', name):
+        return 0.3, 0.35      # gammas ~0.35±0.3, scales/shifts likewise: every branch is live
+    if name.endswith('mat_qkv.weight') or name.endswith('fc1.weight'):
+        return math.sqrt(3.0 / fan_in), 0.0
+    if name.endswith('attn.proj.weight') or name.endswith('fc2.weight'):
+        return math.sqrt(3.0 / fan_in) * 2.0 / math.sqrt(2.0 * depth), 0.0
+    if name == 'head.weight':
+        return 2.0 * math.sqrt(3.0 / fan_in), 0.0
+    if name in ('head.bias',):
+        return 0.2, 0.0
+    if re.search(r'(proj|fc1|fc2)\.bias$', name) and 'blocks.' in name:
+        return 0.05, 0.0
+    # ---- VQVAE -----------------------------------------------------------------------------------------------
+    if name == 'quantize.embedding.weight':
+        return 1.0, 0.0
+    if re.search(r'norm\w*\.weight$', name):
+        return 0.2, 1.0
+    if re.search(r'norm\w*\.bias$', name):
+        return 0.2, 0.0
+    if last == 'weight' and len(shape) == 4:                  # every Conv2d of the VAE (and Phi)
+        return math.sqrt(3.0 / fan_in), 0.0
+    if last == 'bias':
+        return 0.05, 0.0
+    return 0.0, 0.0
+
+
+_KEEP = ('lvl_1L', 'attn_bias_for_masking', 'zero_k_bias', 'ema_vocab_hit_SV')
+
+
+def make_state_dict(shapes: Mapping[str, Tuple[int, ...]], depth: int, seed: int = 0, prefix: str = '') -> Dict[str, np.ndarray]:
+    """Build float32 arrays for every key in `shapes` (buffers in _KEEP are skipped: the module's own values stay).
+
+    `prefix` namespaces the hash stream ('var.' / 'vae.') so equal key names in the two models differ.
+    """
+    out: Dict[str, np.ndarray] = {}
+    for name, shape in shapes.items():
+        if name.endswith(_KEEP):
+            continue
+        amp, off = _rule(name, tuple(shape), depth)
+        if amp == 0.0 and off == 0.0:
+            raise KeyError(f'detinit: no rule for parameter {name!r} {tuple(shape)}')
+        n = int(np.prod(shape)) if len(shape) else 1
+        v = hash_uniform(prefix + name, n, seed) * np.float32(amp) + np.float32(off)
+        out[name] = v.astype(np.float32).reshape(shape)
+    return out
+
+
+def fill_module_(module, depth: int, seed: int = 0, prefix: str = '') -> None:
+    """Overwrite every parameter/buffer of a torch module in place from make_state_dict (strict key match)."""
+    import torch
+    sd = module.state_dict()
+    new = make_state_dict({k: tuple(v.shape) for k, v in sd.items()}, depth=depth, seed=seed, prefix=prefix)
+    with torch.no_grad():
+        for k, arr in new.items():
+            sd[k].copy_(torch.from_numpy(arr).to(sd[k].device))
