@@ -1,0 +1,165 @@
+/* var_hip.h — C ABI of libvar_hip.so: the MI355X (gfx950) kernels of VAR's next-scale sampling path.
+ *
+ * The reference (culiver/VAR) is pure Python on PyTorch: it has no FFI layer.  The drop-in boundary is the
+ * `models` nn.Module API; *under* it the build calls this library through ctypes (var_amd/hip.py).  Each entry
+ * point below names the reference code it replaces (paths relative to the reference repo).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (torch tensors); the library never allocates or
+ *     frees caller-visible memory and keeps no state besides the optional timing table;
+ *   - all matrices are row-major fp32; "ld*" are leading dimensions in elements;
+ *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream); launches are asynchronous;
+ *   - return value: 0 on success, VARHIP_EINVAL (-1) for a shape/argument the kernels do not support,
+ *     -(1000+hipError_t) when the launch itself failed.  No exceptions cross the ABI.
+ *   - the CPU oracle (oracle/var_oracle.c) exports the same functions with prefix `varref_` and no stream
+ *     argument, on HOST pointers: tests drive both with the same arguments.
+ *   - arithmetic contract: dot products are k-ascending fp32 fma chains starting
+ *     from 0 (what v_mfma_f32_32x32x2_f32 computes), then bias, then epilogue, each separately rounded.
+ */
+#ifndef VAR_HIP_H
+#define VAR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VARHIP_EINVAL (-1)
+
+typedef void* varhip_stream_t;
+
+/* library / build info: returns a static string "var_hip <version> gfx950" */
+const char* varhip_version(void);
+
+/* ---- GEMM ------------------------------------------------------------------------------------------------
+ * out[b][m][n] = epi( sum_k A[b][m][k] * W[b][n][k] + bias )          (torch F.linear: x @ W^T + b)
+ * replaces: F.linear at basic_var.py:93 (mat_qkv), :119 (proj), :52 (fc1/fc2), :147,:170 (ada_lin), var.py:124
+ * (head), and the 1x1 convs of basic_vae.py:53,69,71,83,89 (nin_shortcut, qkv, proj_out, the two bmm's).
+ *   epi = VARHIP_EPI_NONE : acc + bias
+ *         VARHIP_EPI_GELU : gelu_tanh(acc + bias)                              (basic_var.py:40,52)
+ *         VARHIP_EPI_RESID: resid[m][n] + (acc + bias) * gamma[m / rows_per_group][n]   (basic_var.py:157-158);
+ *                           gamma == NULL means no scaling: resid + (acc + bias)       (basic_vae.py:60,92)
+ *   bias may be NULL.  bias_per_row != 0: bias is indexed by m instead of n.
+ *   batch >= 1 with element strides sA/sW/sO (sW or sA may be 0 to share an operand); resid/gamma only with batch==1.
+ * Constraints: K % 8 == 0, lda/ldw % 4 == 0, pointers 16-byte aligned. */
+#define VARHIP_EPI_NONE 0
+#define VARHIP_EPI_GELU 1
+#define VARHIP_EPI_RESID 2
+int varhip_gemm_nt_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
+                       float* out, int64_t ldo, int M, int N, int K, int epi,
+                       const float* resid, int64_t ldr, const float* gamma, int64_t ldg, int rows_per_group,
+                       int bias_per_row, int batch, int64_t sA, int64_t sW, int64_t sO, varhip_stream_t stream);
+
+/* y[i] = x[i] * sigmoid(x[i])   — the SiLU in front of every ada_lin (basic_var.py:147,170; var.py:80) */
+int varhip_silu_f32(const float* x, float* y, int64_t n, varhip_stream_t stream);
+
+/* out[b][j] = base[j] + cond[b][j], j < n   — shared AdaLN: ada_gss + cond_BD (basic_var.py:153-154) */
+int varhip_add_bcast_f32(const float* base, const float* cond, float* out, int rows, int n, varhip_stream_t stream);
+
+/* ---- AdaLN -----------------------------------------------------------------------------------------------
+ * out[m][:] = LN(x[m][:]) * (scale[g][:] + 1) + shift[g][:],  g = m / rows_per_group, LN without affine,
+ * biased variance, eps inside the sqrt.   replaces basic_var.py:157,158,174 (ln_wo_grad(...).mul(scale.add(1)).add_(shift)) */
+int varhip_ln_modulate_f32(const float* x, const float* scale, int64_t ld_scale, const float* shift, int64_t ld_shift,
+                           float* out, int M, int C, int rows_per_group, float eps, varhip_stream_t stream);
+
+/* ---- q/k/v post-processing + KV-cache append ------------------------------------------------------------
+ * qkv: [B2*l][3*C] (q | k | v, each H heads x 64).  For every row and head:
+ *   l2norm != 0: q = q/max(|q|,1e-12) * exp(min(scale_mul[h], ln 100)),  k = k/max(|k|,1e-12)   (basic_var.py:101-105)
+ *   l2norm == 0: q = q * plain_scale (attention scale folded into q; basic_var.py:72,117), k unchanged
+ * q -> q_out[B2*l][C]; k,v -> caches [B2][H][Lmax][64] at positions pos0 .. pos0+l-1 (replaces the torch.cat
+ * cache growth of basic_var.py:107-109 by an in-place append). */
+int varhip_qkv_prep_f32(const float* qkv, const float* scale_mul, float plain_scale, int l2norm,
+                        float* q_out, float* kcache, float* vcache,
+                        int B2, int l, int H, int pos0, int Lmax, varhip_stream_t stream);
+
+/* ---- attention of l new queries over curL cached keys (no mask: block-causal by construction) -----------
+ * out[b][t][h*64+c] = sum_j softmax_j(q[b][t][h] . k[b][h][j]) v[b][h][j][c],  j < curL
+ * replaces slow_attn / flash_attn_func / memory_efficient_attention at basic_var.py:111-117 (head_dim 64, scale 1:
+ * the scale is already folded into q by varhip_qkv_prep_f32). */
+int varhip_attn_cached_f32(const float* q, const float* kcache, const float* vcache, float* out,
+                           int B2, int l, int H, int curL, int Lmax, varhip_stream_t stream);
+
+/* ---- classifier-free guidance + top-k/top-p + multinomial(1) -------------------------------------------
+ * logits: [2B][l][V] (rows 0..B-1 conditional, B..2B-1 unconditional).  For row r=(b,t):
+ *   x = (float)(1+t_cfg) * cond - (float)t_cfg * uncond                             (var.py:172-173)
+ *   top_k > 0: x[x < kth_largest(x, top_k)] = -inf                                   (helpers.py:8-10)
+ *   top_p > 0: ascending stable sort, softmax, cumsum (fp64 accumulate, fp32 per element), remove where
+ *              cum <= (float)(1-top_p) except the largest                            (helpers.py:11-15)
+ *   idx = argmax_v softmax(x)[v] / noise[r][v]    (first max)  == torch.multinomial(p, 1, generator) with
+ *              noise = empty_like(p).exponential_(1, generator)                      (helpers.py:19)
+ * idx_out: int64 [B*l].  masked_out (optional, may be NULL): [B*l][V] the filtered logits (what the reference leaves in place).
+ * Constraint: V % 256 == 0, V <= 8192, 0 <= top_k <= V. */
+int varhip_cfg_sample_f32(const float* logits, const float* noise, int64_t* idx_out, float* masked_out,
+                          int B, int l, int V, double t_cfg, int top_k, double top_p, varhip_stream_t stream);
+
+/* ---- multi-scale quantizer step ---------------------------------------------------------------------------
+ * Feature maps are kept channels-last: f_hat[B][P][P][Cv].
+ * (1) h = codebook[idx] as [B][pn][pn][Cv]                                          (var.py:177,182; quant.py:39)
+ * (2) up = bicubic(h -> PxP) via 4-tap tables (tap_idx/tap_w: [P][4], same table for rows and columns; NULL when pn==P)
+ *                                                                                    (quant.py:190, F.interpolate 'bicubic')
+ * (3) f_hat += (1-ratio)*up + ratio*(conv3x3(up; phi_w[Cv][3][3][Cv]) + phi_b)      (quant.py:199-206, :191)
+ * `up` is caller-provided scratch [B][P][P][Cv]. */
+int varhip_quant_accum_f32(const int64_t* idx, const float* codebook, const int32_t* tap_idx, const float* tap_w,
+                           const float* phi_w, const float* phi_b, float ratio,
+                           float* up, float* f_hat, int B, int pn, int P, int Cv, varhip_stream_t stream);
+
+/* (4) next-scale input: pooled = adaptive_avg_pool(f_hat -> pq x pq)  (quant.py:192, F.interpolate 'area');
+ *     x[b][t][:] = x[b+B][t][:] = word_w[C][Cv] . pooled[b][t][:] + word_b + lvl_pos[t][:]     (var.py:185-187)
+ * lvl_pos must already point at row cur_L.  pooled (optional, may be NULL): [B][pq*pq][Cv] copy for inspection. */
+int varhip_next_map_f32(const float* f_hat, const float* word_w, const float* word_b, const float* lvl_pos,
+                        float* x_out, float* pooled, int B, int P, int pq, int C, int Cv, varhip_stream_t stream);
+
+/* lvl_pos[t][:] = lvl_embed[lvl[t]][:] + pos[t][:]     (var.py:153) */
+int varhip_lvl_pos_f32(const float* lvl_embed, const int64_t* lvl, const float* pos, float* out, int L, int C, varhip_stream_t stream);
+
+/* prologue (var.py:151,154): cond[b2][:] = class_emb[b2 < B ? label[b2] : num_classes][:];
+ * x[b2][t][:] = (cond[b2][:] + pos_start[t][:]) + lvl_pos[t][:],  t < first_l */
+int varhip_first_map_f32(const float* class_emb, const int64_t* labels, int num_classes, const float* pos_start,
+                         const float* lvl_pos, float* cond, float* x_out, int B, int C, int first_l, varhip_stream_t stream);
+
+/* ---- VQVAE decoder (channels-last) ----------------------------------------------------------------------
+ * 3x3 convolution, stride 1, zero padding 1 (cross-correlation), w packed [Cout][3][3][Cin]:
+ *   out[b][y][x][co] = sum_{ky,kx,ci} in[b][y+ky-1][x+kx-1][ci] * w[co][ky][kx][ci] + bias[co]  (+ resid[b][y][x][co])
+ *   up2 != 0: `in` is [B][H/2][W/2][Cin] and is read through a nearest-neighbour 2x upsampling
+ *             (basic_vae.py:27-28 Upsample2x: F.interpolate(scale 2,'nearest') then conv)
+ *   out_mode 0: out is [B][H][W][Cout];  out_mode 1: out is [B][Cout][H][W] and holds (clamp(v,-1,1)+1)*0.5
+ *             (vqvae.py:63 clamp_ and var.py:190 add_(1).mul_(0.5) fused into the last conv)
+ * replaces every Conv2d(k=3) of basic_vae.py (ResnetBlock :48,:51; conv_in :180; conv_out :208; Upsample2x :25)
+ * and vqvae.py:49 post_quant_conv.   Constraint: Cin % 8 == 0. */
+int varhip_conv3x3_nhwc_f32(const float* in, const float* w, const float* bias, const float* resid, float* out,
+                            int B, int H, int W, int Cin, int Cout, int up2, int out_mode, varhip_stream_t stream);
+
+/* GroupNorm statistics: stats[b][g] = {mean, rstd} over (HW, C/G) with biased variance (basic_vae.py:18-19, eps 1e-6).
+ * scratch: caller-provided, at least varhip_gn_scratch_elems(B,HW,C,G) doubles. */
+int64_t varhip_gn_scratch_elems(int B, int HW, int C, int G);
+int varhip_gn_stats_f32(const float* x, float* stats, double* scratch, int B, int HW, int C, int G, float eps, varhip_stream_t stream);
+/* out = ((x - mean) * rstd) * gamma[c] + beta[c], then SiLU if silu != 0   (basic_vae.py:58,59,74,225) */
+int varhip_gn_apply_f32(const float* x, const float* stats, const float* gamma, const float* beta, float* out,
+                        int B, int HW, int C, int G, int silu, varhip_stream_t stream);
+
+/* out[r][:] = softmax(x[r][:] * scale), rows of length n   (basic_vae.py:83-84: bmm(...).mul_(w_ratio); softmax(dim=2)) */
+int varhip_softmax_rows_f32(const float* x, float* out, int64_t rows, int n, float scale, varhip_stream_t stream);
+
+/* [B][C][H][W] <-> [B][H][W][C] copies for the API edge (f_hat is NCHW in the reference's API) */
+int varhip_nchw_to_nhwc_f32(const float* in, float* out, int B, int C, int HW, varhip_stream_t stream);
+int varhip_nhwc_to_nchw_f32(const float* in, float* out, int B, int C, int HW, varhip_stream_t stream);
+
+/* ---- nearest-codebook lookup (encode side; quant.py:150-157) --------------------------------------------
+ * idx[n] = argmin_v ( |z_n|^2 + |e_v|^2 - 2 z_n.e_v ), first index on ties; z: [N][Cv], codebook: [V][Cv] */
+int varhip_nearest_code_f32(const float* z, const float* codebook, int64_t* idx_out, int N, int V, int Cv, varhip_stream_t stream);
+
+/* ---- per-kernel timing (bench.py's roofline leg) -----------------------------------------------------------
+ * When enabled, every launch is bracketed by hipEvents on its own stream and its algorithmic FLOPs and bytes are
+ * accumulated per kernel family.  varhip_timing_read synchronises the recorded events.
+ * families: 0 gemm, 1 conv3x3, 2 attn, 3 sampler, 4 ln, 5 qkv_prep, 6 gn, 7 other.  Returns the number of families. */
+#define VARHIP_NFAM 8
+int varhip_timing_enable(int on);
+int varhip_timing_reset(void);
+int varhip_timing_read(double* ms, double* flops, double* bytes, int64_t* launches);
+const char* varhip_timing_name(int family);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VAR_HIP_H */

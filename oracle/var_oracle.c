@@ -1,0 +1,541 @@
+/* var_oracle.c — CPU oracle for the VAR next-scale sampling path.  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the product
+ * (var_amd/, models/) never does.  It restates, in plain scalar C, the algorithm of the reference
+ * (culiver/VAR, all Python/PyTorch) for the path VAR.autoregressive_infer_cfg -> VectorQuantizer2 -> VQVAE decode;
+ * every function cites the reference lines it follows.  The arithmetic PyTorch delegates to ATen (oneDNN sgemm,
+ * vectorised reductions, Sleef exp) has no specified rounding order; this oracle fixes one:
+ *   - dot products: fp32 fma chain, k ascending, from 0;   - exp & friends: include/var_math.h;
+ *   - row reductions: the "canonical" lane-strided + butterfly orders defined below.
+ * Parity pinning: tests/test_oracle_vs_golden.py checks this oracle against fixtures produced by running the
+ * reference itself (tools/gen_golden.py): token ids equal, logits/pixels to fp32 rounding noise.
+ *
+ * Signatures mirror include/var_hip.h (prefix varref_, host pointers, no stream).
+ * Build: oracle/Makefile (gcc -O2 -ffp-contract=off -mavx2 -mfma -fopenmp).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../include/var_math.h"
+
+#define VARHIP_EINVAL (-1)
+#define EPI_NONE 0
+#define EPI_GELU 1
+#define EPI_RESID 2
+
+/* ---- canonical reductions ---------------------------------------------------------------------------------------
+ * W64(vw): element i goes to partial (i / vw) % 64, partials accumulate in ascending i from 0.0f, then an xor
+ * butterfly (offsets 32,16,8,4,2,1) — exactly what one 64-lane wavefront does with vw-wide loads and __shfl_xor. */
+static float canon_sum64(const float* x, int n, int vw) {
+    float p[64], q[64];
+    for (int j = 0; j < 64; ++j) p[j] = 0.0f;
+    for (int i = 0; i < n; ++i) { int j = (i / vw) & 63; p[j] = p[j] + x[i]; }
+    for (int off = 32; off >= 1; off >>= 1) {
+        for (int j = 0; j < 64; ++j) q[j] = p[j] + p[j ^ off];
+        memcpy(p, q, sizeof(p));
+    }
+    return p[0];
+}
+/* W256: 256 threads, thread t sums i = t, t+256, ...; butterfly inside each 64-lane wave; waves added in order. */
+static float canon_sum256(const float* x, int n) {
+    float p[256], q[64];
+    for (int j = 0; j < 256; ++j) p[j] = 0.0f;
+    for (int i = 0; i < n; ++i) p[i & 255] = p[i & 255] + x[i];
+    float w[4];
+    for (int wv = 0; wv < 4; ++wv) {
+        float* pw = p + 64 * wv;
+        for (int off = 32; off >= 1; off >>= 1) {
+            for (int j = 0; j < 64; ++j) q[j] = pw[j] + pw[j ^ off];
+            memcpy(pw, q, sizeof(q));
+        }
+        w[wv] = pw[0];
+    }
+    return ((w[0] + w[1]) + w[2]) + w[3];
+}
+
+const char* varref_version(void) { return "var_oracle 0.1 (cpu restatement)"; }
+
+/* ================================================================================================================
+ * GEMM  out = epi(A . W^T + bias)        reference: F.linear at basic_var.py:93,119,52,147,170; var.py:124;
+ * 1x1 convs and bmm's of basic_vae.py:53,69,71,83,89.   Wt is W transposed to [K][N] (so the n loop vectorises;
+ * each out[m][n] is still its own k-ascending fma chain). */
+static void gemm_kn_core(const float* A, int64_t lda, const float* Wt, int64_t ldwt, const float* bias, float* out, int64_t ldo,
+                         int M, int N, int K, int epi, const float* resid, int64_t ldr, const float* gamma, int64_t ldg,
+                         int rows_per_group, int bias_per_row) {
+    const int NB = 256;
+    int nblk = (N + NB - 1) / NB;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int m = 0; m < M; ++m) {
+        for (int nb = 0; nb < nblk; ++nb) {
+            int n0 = nb * NB, n1 = n0 + NB < N ? n0 + NB : N, w = n1 - n0;
+            float acc[256];
+            for (int j = 0; j < w; ++j) acc[j] = 0.0f;
+            const float* a = A + (int64_t)m * lda;
+            for (int k = 0; k < K; ++k) {
+                float av = a[k];
+                const float* wr = Wt + (int64_t)k * ldwt + n0;
+#pragma omp simd
+                for (int j = 0; j < w; ++j) acc[j] = vm_fma(av, wr[j], acc[j]);
+            }
+            float* o = out + (int64_t)m * ldo + n0;
+            for (int j = 0; j < w; ++j) {
+                float v = acc[j];
+                if (bias) v = v + (bias_per_row ? bias[m] : bias[n0 + j]);
+                if (epi == EPI_GELU) v = vm_gelu_tanh(v);
+                else if (epi == EPI_RESID) {
+                    if (gamma) v = v * gamma[(int64_t)(m / rows_per_group) * ldg + n0 + j];
+                    v = resid[(int64_t)m * ldr + n0 + j] + v;
+                }
+                o[j] = v;
+            }
+        }
+    }
+}
+
+static float* transpose_nk(const float* W, int64_t ldw, int N, int K) {
+    float* t = (float*)malloc(sizeof(float) * (size_t)N * K);
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < K; ++k)
+        for (int n = 0; n < N; ++n) t[(int64_t)k * N + n] = W[(int64_t)n * ldw + k];
+    return t;
+}
+
+int varref_gemm_nt_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
+                       float* out, int64_t ldo, int M, int N, int K, int epi,
+                       const float* resid, int64_t ldr, const float* gamma, int64_t ldg, int rows_per_group,
+                       int bias_per_row, int batch, int64_t sA, int64_t sW, int64_t sO) {
+    if (M < 0 || N <= 0 || K <= 0 || batch < 1) return VARHIP_EINVAL;
+    if (batch > 1 && (resid || gamma)) return VARHIP_EINVAL;
+    if (epi == EPI_RESID && !resid) return VARHIP_EINVAL;
+    if (rows_per_group <= 0) rows_per_group = 1;
+    float* wt = NULL;
+    for (int b = 0; b < batch; ++b) {
+        if (b == 0 || sW != 0) { free(wt); wt = transpose_nk(W + b * sW, ldw, N, K); }
+        gemm_kn_core(A + b * sA, lda, wt, N, bias, out + b * sO, ldo, M, N, K, epi, resid, ldr, gamma, ldg, rows_per_group, bias_per_row);
+    }
+    free(wt);
+    return 0;
+}
+
+/* same, with the weight already transposed to [K][N] (the oracle driver caches transposes; not part of the HIP ABI) */
+int varref_gemm_kn_f32(const float* A, int64_t lda, const float* Wt, int64_t ldwt, const float* bias,
+                       float* out, int64_t ldo, int M, int N, int K, int epi,
+                       const float* resid, int64_t ldr, const float* gamma, int64_t ldg, int rows_per_group) {
+    if (rows_per_group <= 0) rows_per_group = 1;
+    gemm_kn_core(A, lda, Wt, ldwt, bias, out, ldo, M, N, K, epi, resid, ldr, gamma, ldg, rows_per_group, 0);
+    return 0;
+}
+
+/* nn.SiLU in front of ada_lin (basic_var.py:147,170; var.py:80) */
+int varref_silu_f32(const float* x, float* y, int64_t n) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) y[i] = vm_silu(x[i]);
+    return 0;
+}
+
+/* shared AdaLN: ada_gss + cond_BD (basic_var.py:153-154) */
+int varref_add_bcast_f32(const float* base, const float* cond, float* out, int rows, int n) {
+    for (int r = 0; r < rows; ++r)
+        for (int j = 0; j < n; ++j) out[(int64_t)r * n + j] = base[j] + cond[(int64_t)r * n + j];
+    return 0;
+}
+
+/* ln_wo_grad(x).mul(scale.add(1)).add_(shift)   (basic_var.py:157,158,174; LayerNorm eps 1e-6, no affine: var.py:82, basic_var.py:141) */
+int varref_ln_modulate_f32(const float* x, const float* scale, int64_t ld_scale, const float* shift, int64_t ld_shift,
+                           float* out, int M, int C, int rows_per_group, float eps) {
+    if (C <= 0 || rows_per_group <= 0) return VARHIP_EINVAL;
+#pragma omp parallel for schedule(static)
+    for (int m = 0; m < M; ++m) {
+        const float* xr = x + (int64_t)m * C;
+        float* d = (float*)malloc(sizeof(float) * 2 * C);
+        float* d2 = d + C;
+        float mean = canon_sum64(xr, C, 4) / (float)C;
+        for (int i = 0; i < C; ++i) { d[i] = xr[i] - mean; d2[i] = d[i] * d[i]; }
+        float var = canon_sum64(d2, C, 4) / (float)C;
+        float rstd = 1.0f / vm_sqrt(var + eps);
+        const float* sc = scale + (int64_t)(m / rows_per_group) * ld_scale;
+        const float* sh = shift + (int64_t)(m / rows_per_group) * ld_shift;
+        for (int i = 0; i < C; ++i) out[(int64_t)m * C + i] = (d[i] * rstd) * (sc[i] + 1.0f) + sh[i];
+        free(d);
+    }
+    return 0;
+}
+
+/* SelfAttention.forward up to the cache append (basic_var.py:98-109), head_dim 64 */
+int varref_qkv_prep_f32(const float* qkv, const float* scale_mul, float plain_scale, int l2norm,
+                        float* q_out, float* kcache, float* vcache, int B2, int l, int H, int pos0, int Lmax) {
+    if (pos0 < 0 || pos0 + l > Lmax) return VARHIP_EINVAL;
+    const int C = H * 64;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B2; ++b) {
+        for (int t = 0; t < l; ++t) {
+            const float* row = qkv + ((int64_t)b * l + t) * 3 * C;
+            for (int h = 0; h < H; ++h) {
+                const float* q = row + h * 64; const float* k = row + C + h * 64; const float* v = row + 2 * C + h * 64;
+                float* qo = q_out + ((int64_t)b * l + t) * C + h * 64;
+                float* ko = kcache + (((int64_t)b * H + h) * Lmax + pos0 + t) * 64;
+                float* vo = vcache + (((int64_t)b * H + h) * Lmax + pos0 + t) * 64;
+                if (l2norm) {
+                    float sq[64];
+                    for (int c = 0; c < 64; ++c) sq[c] = q[c] * q[c];
+                    float dq = vm_max(vm_sqrt(canon_sum64(sq, 64, 1)), 1e-12f);       /* F.normalize eps */
+                    for (int c = 0; c < 64; ++c) sq[c] = k[c] * k[c];
+                    float dk = vm_max(vm_sqrt(canon_sum64(sq, 64, 1)), 1e-12f);
+                    float sm = vm_exp(vm_min(scale_mul[h], 4.605170249938965f));     /* clamp_max(log 100).exp(): basic_var.py:70,102 */
+                    for (int c = 0; c < 64; ++c) { qo[c] = (q[c] / dq) * sm; ko[c] = k[c] / dk; vo[c] = v[c]; }
+                } else {
+                    for (int c = 0; c < 64; ++c) { qo[c] = q[c] * plain_scale; ko[c] = k[c]; vo[c] = v[c]; }
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+/* slow_attn / SDPA without mask over the cached keys (basic_var.py:111-117).  Row sum of the softmax numerators:
+ * (sum over even key positions) + (sum over odd key positions), each ascending — see DESIGN.md §Numerics. */
+int varref_attn_cached_f32(const float* q, const float* kcache, const float* vcache, float* out,
+                           int B2, int l, int H, int curL, int Lmax) {
+    if (curL <= 0 || curL > Lmax) return VARHIP_EINVAL;
+    const int C = H * 64;
+#pragma omp parallel for collapse(2) schedule(dynamic, 4)
+    for (int b = 0; b < B2; ++b) {
+        for (int h = 0; h < H; ++h) {
+            const float* K = kcache + ((int64_t)b * H + h) * Lmax * 64;
+            const float* Vv = vcache + ((int64_t)b * H + h) * Lmax * 64;
+            float* s = (float*)malloc(sizeof(float) * curL);
+            for (int t = 0; t < l; ++t) {
+                const float* qr = q + ((int64_t)b * l + t) * C + h * 64;
+                float m = -INFINITY;
+                for (int j = 0; j < curL; ++j) {
+                    float acc = 0.0f;
+                    for (int d = 0; d < 64; ++d) acc = vm_fma(K[(int64_t)j * 64 + d], qr[d], acc);
+                    s[j] = acc; m = vm_max(m, acc);
+                }
+                float le = 0.0f, lo = 0.0f;
+                for (int j = 0; j < curL; ++j) {
+                    s[j] = vm_exp(s[j] - m);
+                    if (j & 1) lo = lo + s[j]; else le = le + s[j];
+                }
+                float lsum = le + lo;
+                float* o = out + ((int64_t)b * l + t) * C + h * 64;
+                float acc[64];
+                for (int c = 0; c < 64; ++c) acc[c] = 0.0f;
+                for (int j = 0; j < curL; ++j) {
+                    float pj = s[j];
+                    const float* vr = Vv + (int64_t)j * 64;
+#pragma omp simd
+                    for (int c = 0; c < 64; ++c) acc[c] = vm_fma(pj, vr[c], acc[c]);
+                }
+                for (int c = 0; c < 64; ++c) o[c] = acc[c] / lsum;
+            }
+            free(s);
+        }
+    }
+    return 0;
+}
+
+/* CFG (var.py:172-173) + sample_with_top_k_top_p_ (helpers.py:6-19) + torch.multinomial(n=1) == argmax(p / Exp(1) noise) */
+typedef struct { uint32_t key; int32_t idx; } sortent_t;
+static int cmp_sortent(const void* a, const void* b) {
+    const sortent_t* x = (const sortent_t*)a; const sortent_t* y = (const sortent_t*)b;
+    if (x->key != y->key) return x->key < y->key ? -1 : 1;
+    return x->idx < y->idx ? -1 : (x->idx > y->idx);
+}
+int varref_cfg_sample_f32(const float* logits, const float* noise, int64_t* idx_out, float* masked_out,
+                          int B, int l, int V, double t_cfg, int top_k, double top_p) {
+    if (V <= 0 || (V & 255) || V > 8192 || top_k < 0 || top_k > V) return VARHIP_EINVAL;
+    const float ca = (float)(1.0 + t_cfg), cb = (float)t_cfg, thr = (float)(1.0 - top_p);
+    int64_t rows = (int64_t)B * l;
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int64_t r = 0; r < rows; ++r) {
+        const float* lc = logits + r * V; const float* lu = logits + (rows + r) * V;
+        float* x = (float*)malloc(sizeof(float) * 2 * V); float* e = x + V;
+        for (int i = 0; i < V; ++i) { float a = ca * lc[i]; float b = cb * lu[i]; x[i] = a - b; }
+        if (top_k > 0) {                                   /* helpers.py:8-10: strict '<' keeps ties with the k-th value */
+            uint32_t* keys = (uint32_t*)malloc(sizeof(uint32_t) * V);
+            for (int i = 0; i < V; ++i) keys[i] = vm_float_key(x[i]);
+            /* k-th largest by counting from the top: exact selection via full sort of a copy */
+            sortent_t* tmp = (sortent_t*)malloc(sizeof(sortent_t) * V);
+            for (int i = 0; i < V; ++i) { tmp[i].key = keys[i]; tmp[i].idx = i; }
+            qsort(tmp, V, sizeof(sortent_t), cmp_sortent);
+            float kth = x[tmp[V - top_k].idx];
+            for (int i = 0; i < V; ++i) if (x[i] < kth) x[i] = -INFINITY;
+            free(tmp); free(keys);
+        }
+        float m = -INFINITY;
+        for (int i = 0; i < V; ++i) m = vm_max(m, x[i]);
+        if (top_p > 0.0) {                                 /* helpers.py:11-15 */
+            for (int i = 0; i < V; ++i) e[i] = vm_exp(x[i] - m);
+            float S = canon_sum256(e, V);
+            sortent_t* srt = (sortent_t*)malloc(sizeof(sortent_t) * V);
+            for (int i = 0; i < V; ++i) { srt[i].key = vm_float_key(x[i]); srt[i].idx = i; }
+            qsort(srt, V, sizeof(sortent_t), cmp_sortent);          /* ascending, stable by index */
+            double c = 0.0;
+            for (int s = 0; s < V - 1; ++s) {                         /* the last (largest) is never removed */
+                int i = srt[s].idx;
+                c += (double)(e[i] / S);
+                if ((float)c <= thr) x[i] = -INFINITY; else break;    /* cum is non-decreasing: the removed set is a prefix */
+            }
+            free(srt);
+        }
+        for (int i = 0; i < V; ++i) e[i] = vm_exp(x[i] - m);
+        float S = canon_sum256(e, V);
+        const float* qn = noise + r * V;
+        int best = 0; float bestv = 0.0f; int have = 0, best_nan = 0;
+        for (int i = 0; i < V; ++i) {
+            float rv = (e[i] / S) / qn[i];
+            int isn = (rv != rv);
+            if (!have) { best = i; bestv = rv; best_nan = isn; have = 1; }
+            else if (!best_nan && (isn || rv > bestv)) { best = i; bestv = rv; best_nan = isn; }   /* torch.argmax: NaN wins, first max */
+        }
+        idx_out[r] = best;
+        if (masked_out) memcpy(masked_out + r * V, x, sizeof(float) * V);
+        free(x);
+    }
+    return 0;
+}
+
+/* codebook gather + bicubic up + Phi + f_hat accumulate  (var.py:177,182; quant.py:187-196, 199-206) */
+int varref_quant_accum_f32(const int64_t* idx, const float* codebook, const int32_t* tap_idx, const float* tap_w,
+                           const float* phi_w, const float* phi_b, float ratio,
+                           float* up, float* f_hat, int B, int pn, int P, int Cv) {
+    if ((pn != P) && (!tap_idx || !tap_w)) return VARHIP_EINVAL;
+    const float keep = 1.0f - ratio;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int y = 0; y < P; ++y)
+            for (int x = 0; x < P; ++x) {
+                float* u = up + (((int64_t)b * P + y) * P + x) * Cv;
+                if (pn == P) {
+                    const float* e = codebook + idx[(int64_t)b * pn * pn + y * pn + x] * Cv;
+                    for (int c = 0; c < Cv; ++c) u[c] = e[c];
+                } else {
+                    const int32_t* iy = tap_idx + y * 4; const float* wy = tap_w + y * 4;
+                    const int32_t* ix = tap_idx + x * 4; const float* wx = tap_w + x * 4;
+                    for (int c = 0; c < Cv; ++c) {
+                        float rr[4];
+                        for (int a = 0; a < 4; ++a) {
+                            const int64_t* ir = idx + (int64_t)b * pn * pn + iy[a] * pn;
+                            float acc = codebook[ir[ix[0]] * Cv + c] * wx[0];
+                            acc = vm_fma(codebook[ir[ix[1]] * Cv + c], wx[1], acc);
+                            acc = vm_fma(codebook[ir[ix[2]] * Cv + c], wx[2], acc);
+                            acc = vm_fma(codebook[ir[ix[3]] * Cv + c], wx[3], acc);
+                            rr[a] = acc;
+                        }
+                        float o = rr[0] * wy[0];
+                        o = vm_fma(rr[1], wy[1], o); o = vm_fma(rr[2], wy[2], o); o = vm_fma(rr[3], wy[3], o);
+                        u[c] = o;
+                    }
+                }
+            }
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int y = 0; y < P; ++y)
+            for (int x = 0; x < P; ++x) {
+                const float* u0 = up + (((int64_t)b * P + y) * P + x) * Cv;
+                float* f = f_hat + (((int64_t)b * P + y) * P + x) * Cv;
+                for (int co = 0; co < Cv; ++co) {
+                    float acc = 0.0f;
+                    for (int ky = 0; ky < 3; ++ky) {
+                        int yy = y + ky - 1; if (yy < 0 || yy >= P) continue;
+                        for (int kx = 0; kx < 3; ++kx) {
+                            int xx = x + kx - 1; if (xx < 0 || xx >= P) continue;
+                            const float* u = up + (((int64_t)b * P + yy) * P + xx) * Cv;
+                            const float* w = phi_w + (((int64_t)co * 3 + ky) * 3 + kx) * Cv;
+                            for (int ci = 0; ci < Cv; ++ci) acc = vm_fma(u[ci], w[ci], acc);
+                        }
+                    }
+                    float conv = acc + phi_b[co];
+                    float hmix = u0[co] * keep + conv * ratio;       /* Phi.forward: h*(1-r) + conv(h)*r  (quant.py:205-206) */
+                    f[co] = f[co] + hmix;                            /* f_hat.add_(h)  (quant.py:191,195) */
+                }
+            }
+    return 0;
+}
+
+/* area-downsample to the next scale + word_embed + level/position embedding, duplicated for CFG (quant.py:192; var.py:185-187) */
+int varref_next_map_f32(const float* f_hat, const float* word_w, const float* word_b, const float* lvl_pos,
+                        float* x_out, float* pooled, int B, int P, int pq, int C, int Cv) {
+    if (pq <= 0 || pq > P) return VARHIP_EINVAL;
+    int lq = pq * pq;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int t = 0; t < lq; ++t) {
+            int oy = t / pq, ox = t % pq;
+            int y0 = (oy * P) / pq, y1 = ((oy + 1) * P + pq - 1) / pq;      /* adaptive_avg_pool2d windows == interpolate(mode='area') */
+            int x0 = (ox * P) / pq, x1 = ((ox + 1) * P + pq - 1) / pq;
+            float pl[64];
+            for (int c = 0; c < Cv; ++c) {
+                float s = 0.0f;
+                for (int y = y0; y < y1; ++y)
+                    for (int x = x0; x < x1; ++x) s = s + f_hat[(((int64_t)b * P + y) * P + x) * Cv + c];
+                pl[c] = (s / (float)(y1 - y0)) / (float)(x1 - x0);
+                if (pooled) pooled[((int64_t)b * lq + t) * Cv + c] = pl[c];
+            }
+            for (int n = 0; n < C; ++n) {
+                float acc = 0.0f;
+                const float* w = word_w + (int64_t)n * Cv;
+                for (int c = 0; c < Cv; ++c) acc = vm_fma(pl[c], w[c], acc);
+                float v = (acc + word_b[n]) + lvl_pos[(int64_t)t * C + n];
+                x_out[((int64_t)b * lq + t) * C + n] = v;
+                x_out[((int64_t)(b + B) * lq + t) * C + n] = v;        /* .repeat(2,1,1) */
+            }
+        }
+    return 0;
+}
+
+/* lvl_embed(lvl_1L) + pos_1LC  (var.py:153) */
+int varref_lvl_pos_f32(const float* lvl_embed, const int64_t* lvl, const float* pos, float* out, int L, int C) {
+    for (int t = 0; t < L; ++t)
+        for (int n = 0; n < C; ++n) out[(int64_t)t * C + n] = lvl_embed[lvl[t] * C + n] + pos[(int64_t)t * C + n];
+    return 0;
+}
+
+/* sos / cond_BD and the first token map (var.py:151,154) */
+int varref_first_map_f32(const float* class_emb, const int64_t* labels, int num_classes, const float* pos_start,
+                         const float* lvl_pos, float* cond, float* x_out, int B, int C, int first_l) {
+    for (int b2 = 0; b2 < 2 * B; ++b2) {
+        int64_t cls = b2 < B ? labels[b2] : num_classes;
+        if (cls < 0 || cls > num_classes) return VARHIP_EINVAL;
+        for (int n = 0; n < C; ++n) cond[(int64_t)b2 * C + n] = class_emb[cls * C + n];
+        for (int t = 0; t < first_l; ++t)
+            for (int n = 0; n < C; ++n)
+                x_out[((int64_t)b2 * first_l + t) * C + n] = (cond[(int64_t)b2 * C + n] + pos_start[(int64_t)t * C + n]) + lvl_pos[(int64_t)t * C + n];
+    }
+    return 0;
+}
+
+/* Conv2d k=3 s=1 p=1 in channels-last form (basic_vae.py:25,48,51,180,208; vqvae.py:49).  wt is the weight
+ * re-laid as [3][3][Cin][Cout] so the co loop vectorises; each out element is one (ky,kx,ci)-ascending fma chain. */
+static void conv3x3_core(const float* in, const float* wt, const float* bias, const float* resid, float* out,
+                         int B, int H, int W, int Cin, int Cout, int up2, int out_mode) {
+    int Hi = up2 ? H / 2 : H, Wi = up2 ? W / 2 : W;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int y = 0; y < H; ++y) {
+            float* acc = (float*)malloc(sizeof(float) * Cout);
+            for (int x = 0; x < W; ++x) {
+                for (int co = 0; co < Cout; ++co) acc[co] = 0.0f;
+                for (int ky = 0; ky < 3; ++ky) {
+                    int yy = y + ky - 1; if (yy < 0 || yy >= H) continue;
+                    for (int kx = 0; kx < 3; ++kx) {
+                        int xx = x + kx - 1; if (xx < 0 || xx >= W) continue;
+                        int sy = up2 ? yy >> 1 : yy, sx = up2 ? xx >> 1 : xx;     /* nearest 2x: src = dst // 2 */
+                        const float* ip = in + (((int64_t)b * Hi + sy) * Wi + sx) * Cin;
+                        const float* wp = wt + ((int64_t)(ky * 3 + kx) * Cin) * Cout;
+                        for (int ci = 0; ci < Cin; ++ci) {
+                            float a = ip[ci];
+                            const float* wr = wp + (int64_t)ci * Cout;
+#pragma omp simd
+                            for (int co = 0; co < Cout; ++co) acc[co] = vm_fma(a, wr[co], acc[co]);
+                        }
+                    }
+                }
+                for (int co = 0; co < Cout; ++co) {
+                    float v = acc[co] + bias[co];
+                    if (resid) v = v + resid[(((int64_t)b * H + y) * W + x) * Cout + co];
+                    if (out_mode == 1) {
+                        v = vm_min(vm_max(v, -1.0f), 1.0f);                       /* vqvae.py:63 clamp_(-1,1) */
+                        out[(((int64_t)b * Cout + co) * H + y) * W + x] = (v + 1.0f) * 0.5f;   /* var.py:190 add_(1).mul_(0.5) */
+                    } else out[(((int64_t)b * H + y) * W + x) * Cout + co] = v;
+                }
+            }
+            free(acc);
+        }
+}
+
+int varref_conv3x3_nhwc_f32(const float* in, const float* w, const float* bias, const float* resid, float* out,
+                            int B, int H, int W, int Cin, int Cout, int up2, int out_mode) {
+    if (up2 && ((H & 1) || (W & 1))) return VARHIP_EINVAL;
+    float* wt = (float*)malloc(sizeof(float) * 9 * (size_t)Cin * Cout);     /* [Cout][3][3][Cin] -> [3][3][Cin][Cout] */
+    for (int co = 0; co < Cout; ++co)
+        for (int t = 0; t < 9; ++t)
+            for (int ci = 0; ci < Cin; ++ci) wt[((int64_t)t * Cin + ci) * Cout + co] = w[((int64_t)co * 9 + t) * Cin + ci];
+    conv3x3_core(in, wt, bias, resid, out, B, H, W, Cin, Cout, up2, out_mode);
+    free(wt);
+    return 0;
+}
+
+int64_t varref_gn_scratch_elems(int B, int HW, int C, int G) { (void)HW; (void)C; return (int64_t)B * G * 2; }
+
+/* GroupNorm(32, C, eps=1e-6) statistics (basic_vae.py:18-19): biased variance over (HW, C/G); two-pass in double */
+int varref_gn_stats_f32(const float* x, float* stats, double* scratch, int B, int HW, int C, int G, float eps) {
+    (void)scratch;
+    if (G <= 0 || C % G) return VARHIP_EINVAL;
+    int cpg = C / G;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int g = 0; g < G; ++g) {
+            double s = 0.0;
+            for (int p = 0; p < HW; ++p)
+                for (int c = 0; c < cpg; ++c) s += (double)x[((int64_t)b * HW + p) * C + g * cpg + c];
+            double n = (double)HW * cpg, mean = s / n, v = 0.0;
+            for (int p = 0; p < HW; ++p)
+                for (int c = 0; c < cpg; ++c) { double d = (double)x[((int64_t)b * HW + p) * C + g * cpg + c] - mean; v += d * d; }
+            stats[((int64_t)b * G + g) * 2 + 0] = (float)mean;
+            stats[((int64_t)b * G + g) * 2 + 1] = (float)(1.0 / sqrt(v / n + (double)eps));
+        }
+    return 0;
+}
+
+int varref_gn_apply_f32(const float* x, const float* stats, const float* gamma, const float* beta, float* out,
+                        int B, int HW, int C, int G, int silu) {
+    int cpg = C / G;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int p = 0; p < HW; ++p)
+            for (int c = 0; c < C; ++c) {
+                const float* st = stats + ((int64_t)b * G + c / cpg) * 2;
+                float v = ((x[((int64_t)b * HW + p) * C + c] - st[0]) * st[1]) * gamma[c] + beta[c];
+                out[((int64_t)b * HW + p) * C + c] = silu ? vm_silu(v) : v;
+            }
+    return 0;
+}
+
+/* softmax over the last dim after scaling (basic_vae.py:83-84) */
+int varref_softmax_rows_f32(const float* x, float* out, int64_t rows, int n, float scale) {
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < rows; ++r) {
+        float* e = (float*)malloc(sizeof(float) * n);
+        float m = -INFINITY;
+        for (int i = 0; i < n; ++i) { e[i] = x[r * n + i] * scale; m = vm_max(m, e[i]); }
+        for (int i = 0; i < n; ++i) e[i] = vm_exp(e[i] - m);
+        float S = canon_sum64(e, n, 1);
+        for (int i = 0; i < n; ++i) out[r * n + i] = e[i] / S;
+        free(e);
+    }
+    return 0;
+}
+
+int varref_nchw_to_nhwc_f32(const float* in, float* out, int B, int C, int HW) {
+    for (int b = 0; b < B; ++b) for (int c = 0; c < C; ++c) for (int p = 0; p < HW; ++p)
+        out[((int64_t)b * HW + p) * C + c] = in[((int64_t)b * C + c) * HW + p];
+    return 0;
+}
+int varref_nhwc_to_nchw_f32(const float* in, float* out, int B, int C, int HW) {
+    for (int b = 0; b < B; ++b) for (int c = 0; c < C; ++c) for (int p = 0; p < HW; ++p)
+        out[((int64_t)b * C + c) * HW + p] = in[((int64_t)b * HW + p) * C + c];
+    return 0;
+}
+
+/* nearest codebook entry (quant.py:155-157): d = |z|^2 + |e|^2 - 2 z.e, argmin, first index on ties */
+int varref_nearest_code_f32(const float* z, const float* codebook, int64_t* idx_out, int N, int V, int Cv) {
+    float* ee = (float*)malloc(sizeof(float) * V);
+    for (int v = 0; v < V; ++v) { float a = 0.0f; for (int c = 0; c < Cv; ++c) a = vm_fma(codebook[(int64_t)v * Cv + c], codebook[(int64_t)v * Cv + c], a); ee[v] = a; }
+#pragma omp parallel for schedule(static)
+    for (int n = 0; n < N; ++n) {
+        const float* zr = z + (int64_t)n * Cv;
+        float zz = 0.0f; for (int c = 0; c < Cv; ++c) zz = vm_fma(zr[c], zr[c], zz);
+        int best = 0; float bd = INFINITY;
+        for (int v = 0; v < V; ++v) {
+            float dot = 0.0f; for (int c = 0; c < Cv; ++c) dot = vm_fma(zr[c], codebook[(int64_t)v * Cv + c], dot);
+            float d = (zz + ee[v]) + (-2.0f * dot);
+            if (d < bd) { bd = d; best = v; }
+        }
+        idx_out[n] = best;
+    }
+    free(ee);
+    return 0;
+}

@@ -1,0 +1,92 @@
+"""Pins the CPU oracle (oracle/) against fixtures produced by running the reference itself (tools/gen_golden.py).
+
+The oracle fixes a rounding order where ATen leaves it unspecified, so float outputs agree with the reference to fp32
+rounding noise (tolerances below), while token ids — integer outputs — must agree exactly on these fixtures.
+Tokens are compared twice: free-running, and with the reference's tokens teacher-forced (so that one flipped token
+could not cascade and hide where a disagreement started).
+"""
+import json
+
+import numpy as np
+import pytest
+
+from tests import util
+
+util.ensure_oracle_built()
+from oracle.var_oracle import OracleVAR, lib, _p        # noqa: E402
+
+TINY = ['t_pn123_base', 't_pn12345', 't_nol2', 't_saln', 't_greedy', 't_nofilter', 't_b3_pn1234']
+
+
+def _oracle(meta):
+    var_sd, vae_sd = util.make_weights(meta)
+    return OracleVAR(var_sd, vae_sd, meta['patch_nums'], meta['depth'], attn_l2_norm=meta['attn_l2_norm'], shared_aln=meta['shared_aln'])
+
+
+def _check_case(name, logit_atol, img_atol, free_running=True):
+    z, meta = util.load_case(name)
+    orc = _oracle(meta)
+    noise = util.regen_noise(meta, z)
+    pns = meta['patch_nums']
+    msgs, ok_all = [], True
+    # (1) teacher-forced with the reference's tokens: per-scale logits, own token choices, f_hat, pooled map, image
+    r = orc.run(meta['labels'], noise, meta['cfg'], meta['top_k'], meta['top_p'], force_idx=z['idx'].astype(np.int64))
+    for si, pn in enumerate(pns):
+        lg = r['logits'][si]
+        want = z[f'logits_s{si}']
+        got = lg if meta['full_logits'] else lg[:, sorted({0, pn * pn - 1}), :]
+        ok, m = util.diff_report(f'{name} logits s{si}', got, want, atol=logit_atol, rtol=1e-5); ok_all &= ok; msgs.append(m)
+        cs = abs(lg.astype(np.float64).sum() - float(z['lsum'][si]))
+        if cs > 2e-6 * float(z['labs'][si]) + 1e-3: ok_all = False; msgs.append(f'{name} logits checksum s{si}: off by {cs:.3e}')
+        ok, m = util.diff_report(f'{name} f_hat s{si}', r['f_hat'][si], z[f'f_hat_s{si}'], atol=2e-5, rtol=1e-5); ok_all &= ok; msgs.append(m)
+        if si < len(pns) - 1:
+            ok, m = util.diff_report(f'{name} pooled s{si}', r['pooled'][si], z[f'pool_s{si}'], atol=2e-5, rtol=1e-5); ok_all &= ok; msgs.append(m)
+    ok, m = util.diff_report(f'{name} tokens (teacher-forced)', r['idx'].astype(np.int32), z['idx']); ok_all &= ok; msgs.append(m)
+    ok, m = util.diff_report(f'{name} image', r['img'], z['img'], atol=img_atol); ok_all &= ok; msgs.append(m)
+    if free_running:   # (2) free-running
+        r2 = orc.run(meta['labels'], noise, meta['cfg'], meta['top_k'], meta['top_p'], decode=False)
+        ok, m = util.diff_report(f'{name} tokens (free-running)', r2['idx'].astype(np.int32), z['idx']); ok_all &= ok; msgs.append(m)
+    print('\n'.join(msgs))
+    assert ok_all, '\n'.join(msgs)
+
+
+@pytest.mark.parametrize('name', TINY)
+def test_tiny_cases(name):
+    _check_case(name, logit_atol=2e-4, img_atol=1e-4)
+
+
+def test_baseline_config1_d16_pn123():
+    """BASELINE.json configs[0]: VAR-d16, patch_nums=(1,2,3), B=2"""
+    _check_case('d16_pn123', logit_atol=5e-4, img_atol=1e-3)
+
+
+def test_sampler_vectors(golden_dir):
+    """sample_with_top_k_top_p_ fixtures (helpers.py:6-19): token ids and the kept-set after top-k/top-p must match exactly."""
+    z = np.load(f'{golden_dir}/sampler.npz')
+    cases = json.loads(str(z['meta']))
+    L = lib()
+    for ci, c in enumerate(cases):
+        B, l, V = c['B'], c['l'], c['V']
+        lg = z[f'logits_{ci}']
+        two = np.ascontiguousarray(np.concatenate([lg, np.zeros_like(lg)], 0))      # t_cfg = 0: x = cond exactly
+        idx = np.empty(B * l, np.int64); masked = np.empty((B * l, V), np.float32)
+        rc = L['cfg_sample_f32'](_p(two), _p(np.ascontiguousarray(z[f'noise_{ci}'])), _p(idx), _p(masked), B, l, V, 0.0, c['top_k'], c['top_p'])
+        assert rc == 0
+        kept = np.isfinite(masked).reshape(B, l, V)
+        if c['kind'] == 'ties':
+            # Exact ties straddling the top-p boundary: the reference sorts with torch.sort(stable=False) (helpers.py:12), so WHICH
+            # of the tied entries it drops is ATen-internal; the oracle drops the lowest indices (stable order).  What is specified,
+            # and compared here, is how many entries of each distinct value survive.
+            for r in range(B * l):
+                x = lg.reshape(-1, V)[r]
+                for v in np.unique(x):
+                    m = x == v
+                    assert kept.reshape(-1, V)[r][m].sum() == z[f'kept_{ci}'].reshape(-1, V)[r][m].sum(), f'case {ci} row {r} value {v}'
+            continue
+        assert np.array_equal(kept, z[f'kept_{ci}']), f'case {ci} {c}: kept-set differs in {(kept != z[f"kept_{ci}"]).sum()} places'
+        assert np.array_equal(idx.reshape(B, l), z[f'idx_{ci}']), f'case {ci} {c}: tokens differ'
+
+
+def test_sampler_rejects_bad_args():
+    assert lib()['cfg_sample_f32'](None, None, None, None, 1, 1, 1000, 0.0, 0, 0.0) == -1     # V % 256
+    assert lib()['cfg_sample_f32'](None, None, None, None, 1, 1, 4096, 0.0, 5000, 0.0) == -1  # top_k > V

@@ -1,0 +1,57 @@
+"""ctypes signature table of the C ABI declared in include/var_hip.h.
+
+One table, two consumers: var_amd/hip.py binds `varhip_<name>(..., stream)` in libvar_hip.so (the product),
+oracle/var_oracle.py binds `varref_<name>(...)` in libvar_oracle.so (the CPU checker).  Keeping the argument
+lists in one place is what lets the parity tests drive both libraries with identical arguments.
+"""
+import ctypes as C
+
+P = C.c_void_p
+I = C.c_int
+L = C.c_int64
+F = C.c_float
+D = C.c_double
+
+# name -> argument ctypes (without the trailing stream of the HIP flavour); all return int
+SIGNATURES = {
+    'gemm_nt_f32':       [P, L, P, L, P, P, L, I, I, I, I, P, L, P, L, I, I, I, L, L, L],
+    'silu_f32':          [P, P, L],
+    'add_bcast_f32':     [P, P, P, I, I],
+    'ln_modulate_f32':   [P, P, L, P, L, P, I, I, I, F],
+    'qkv_prep_f32':      [P, P, F, I, P, P, P, I, I, I, I, I],
+    'attn_cached_f32':   [P, P, P, P, I, I, I, I, I],
+    'cfg_sample_f32':    [P, P, P, P, I, I, I, D, I, D],
+    'quant_accum_f32':   [P, P, P, P, P, P, F, P, P, I, I, I, I],
+    'next_map_f32':      [P, P, P, P, P, P, I, I, I, I, I],
+    'lvl_pos_f32':       [P, P, P, P, I, I],
+    'first_map_f32':     [P, P, I, P, P, P, P, I, I, I],
+    'conv3x3_nhwc_f32':  [P, P, P, P, P, I, I, I, I, I, I, I],
+    'gn_stats_f32':      [P, P, P, I, I, I, I, F],
+    'gn_apply_f32':      [P, P, P, P, P, I, I, I, I, I],
+    'softmax_rows_f32':  [P, P, L, I, F],
+    'nchw_to_nhwc_f32':  [P, P, I, I, I],
+    'nhwc_to_nchw_f32':  [P, P, I, I, I],
+    'nearest_code_f32':  [P, P, P, I, I, I],
+}
+
+EPI_NONE, EPI_GELU, EPI_RESID = 0, 1, 2
+EINVAL = -1
+
+
+def bind(lib, prefix: str, with_stream: bool):
+    """Attach argtypes/restype to every ABI function of `lib`; raises AttributeError naming a missing symbol."""
+    fns = {}
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, prefix + name)
+        fn.argtypes = list(args) + ([P] if with_stream else [])
+        fn.restype = I
+        fns[name] = fn
+    gs = getattr(lib, prefix + 'gn_scratch_elems')
+    gs.argtypes = [I, I, I, I]
+    gs.restype = L
+    fns['gn_scratch_elems'] = gs
+    ver = getattr(lib, prefix + 'version')
+    ver.argtypes = []
+    ver.restype = C.c_char_p
+    fns['version'] = ver
+    return fns
