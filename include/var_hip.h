@@ -106,7 +106,7 @@ int varhip_quant_accum_f32(const int64_t* idx, const float* codebook, const int3
 
 /* (4) next-scale input: pooled = adaptive_avg_pool(f_hat -> pq x pq)  (quant.py:192, F.interpolate 'area');
  *     x[b][t][:] = x[b+B][t][:] = word_w[C][Cv] . pooled[b][t][:] + word_b + lvl_pos[t][:]     (var.py:185-187)
- * lvl_pos must already point at row cur_L.  pooled (optional, may be NULL): [B][pq*pq][Cv] copy for inspection. */
+ * lvl_pos must already point at row cur_L.  pooled: caller-provided [B][pq*pq][Cv] buffer (intermediate; kept for inspection). */
 int varhip_next_map_f32(const float* f_hat, const float* word_w, const float* word_b, const float* lvl_pos,
                         float* x_out, float* pooled, int B, int P, int pq, int C, int Cv, varhip_stream_t stream);
 
@@ -126,7 +126,7 @@ int varhip_first_map_f32(const float* class_emb, const int64_t* labels, int num_
  *   out_mode 0: out is [B][H][W][Cout];  out_mode 1: out is [B][Cout][H][W] and holds (clamp(v,-1,1)+1)*0.5
  *             (vqvae.py:63 clamp_ and var.py:190 add_(1).mul_(0.5) fused into the last conv)
  * replaces every Conv2d(k=3) of basic_vae.py (ResnetBlock :48,:51; conv_in :180; conv_out :208; Upsample2x :25)
- * and vqvae.py:49 post_quant_conv.   Constraint: Cin % 8 == 0. */
+ * and vqvae.py:49 post_quant_conv.   Constraint: Cin % 16 == 0. */
 int varhip_conv3x3_nhwc_f32(const float* in, const float* w, const float* bias, const float* resid, float* out,
                             int B, int H, int W, int Cin, int Cout, int up2, int out_mode, varhip_stream_t stream);
 

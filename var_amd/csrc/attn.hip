@@ -1,0 +1,183 @@
+// attn.hip — attention of l new queries over curL cached keys, head_dim 64, fp32 MFMA, no mask (the cache only
+// holds scales <= the current one, so block-causality is implicit: reference basic_var.py:107-117).
+//
+// Structure (per workgroup: one (sample, head), 4 waves x 32 queries):
+//   - "swapped" scores: S^T = K_tile . Q^T with MFMA 32x32x2 (A = keys, B = queries), so each LANE owns one query
+//     (column) and its 16 accumulator registers are 16 keys: row max / row sum are per-lane register reductions
+//     plus one exchange between the two lane halves.
+//   - two passes over the keys instead of an online softmax: pass 1 finds the exact row max, pass 2 recomputes the
+//     scores (bit-identical), takes p = exp(s - m) and accumulates O^T += V^T . P^T.  No rescaling ever happens,
+//     so the result does not depend on the tile size, and the chain over keys is the natural ascending one.
+//   - P feeds the second MFMA straight from the accumulator registers: v_permlane32_swap on register pairs turns the
+//     C-layout (lane half h holds keys 8g+4h+{0..3}) into the B-operand layout (half h holds key 2s+h).
+//   Row-sum order (mirrored by oracle/var_oracle.c): (sum over even keys, ascending) + (sum over odd keys, ascending).
+#include "common.h"
+
+#define KLD 68          // K tile row stride (floats): 64 + 4 -> conflict-free ds_read_b128 / ds_write_b128
+#define VLD 64
+#define OLD 65
+
+template <int E>
+__device__ __forceinline__ void swap_pair(f32x16& p) {      // registers (E, E+1): afterwards E = keys (2s,2s+1), E+1 = keys (2s+4, 2s+5)
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(p[E]), __float_as_uint(p[E + 1]), false, false);
+    p[E] = __uint_as_float(r[0]);
+    p[E + 1] = __uint_as_float(r[1]);
+}
+
+__global__ void __launch_bounds__(256) k_attn_cached(const float* __restrict__ q, const float* __restrict__ kcache, const float* __restrict__ vcache,
+                                                     float* __restrict__ out, int l, int H, int curL, int Lmax) {
+    // one LDS array: K stages | V stages; the Q staging at the start and the O transpose at the end alias it
+    __shared__ __attribute__((aligned(16))) float smem[2 * 32 * KLD + 2 * 32 * VLD];
+    float (*sK)[32 * KLD] = reinterpret_cast<float (*)[32 * KLD]>(smem);
+    float (*sV)[32 * VLD] = reinterpret_cast<float (*)[32 * VLD]>(smem + 2 * 32 * KLD);
+    float (*sO)[32 * OLD] = reinterpret_cast<float (*)[32 * OLD]>(smem);
+    static_assert(4 * 32 * OLD <= 2 * 32 * KLD + 2 * 32 * VLD, "O staging must fit in the K/V stages");
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h2 = lane >> 5;
+    const int b = blockIdx.z, hd = blockIdx.y;
+    const int C = H * 64;
+    const int t0 = (blockIdx.x * 4 + wave) * 32;                   // this wave's first query
+    const float* Kc = kcache + ((int64_t)b * H + hd) * Lmax * 64;
+    const float* Vc = vcache + ((int64_t)b * H + hd) * Lmax * 64;
+    const int ntile = (curL + 31) / 32;
+
+    // staging role of this thread: key row sr (0..31), chunk sc (8 floats)
+    const int sr = tid >> 3, sc = tid & 7;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    // ---- Q fragments: stage the wave's 32x64 query tile through sO (permuted like a K tile), keep 32 floats per lane
+    float qf[32];
+    {
+        float* st = sO[wave];                                       // 32 rows x 64 (+1) floats, used as [row][KLD-free layout]
+        // each lane loads 32 floats of one row: row = lane&31, half (h2) of the 64 dims
+        const int t = t0 + r;
+        const float* src = q + ((int64_t)b * l + (t < l ? t : 0)) * C + hd * 64 + h2 * 32;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {                               // 4 chunks of 8 dims
+            f32x4 a = zero4, bq = zero4;
+            if (t < l) { a = *(const f32x4*)(src + c * 8); bq = *(const f32x4*)(src + c * 8 + 4); }
+            // even k first, then odd k, inside the chunk (see gemm.hip)
+            float* d = st + r * OLD + h2 * 32 + c * 8;
+            d[0] = a[0]; d[1] = a[2]; d[2] = bq[0]; d[3] = bq[2];
+            d[4] = a[1]; d[5] = a[3]; d[6] = bq[1]; d[7] = bq[3];
+        }
+        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) qf[c * 4 + s] = st[r * OLD + c * 8 + h2 * 4 + s];
+        __syncthreads();
+    }
+
+    auto stage_k = [&](int kt, int buf) {
+        const int key = kt * 32 + sr;
+        f32x4 a = zero4, bq = zero4;
+        if (key < curL) { const float* s = Kc + (int64_t)key * 64 + sc * 8; a = *(const f32x4*)s; bq = *(const f32x4*)(s + 4); }
+        float* d = &sK[buf][sr * KLD + sc * 8];
+        const f32x4 ev = {a[0], a[2], bq[0], bq[2]}, od = {a[1], a[3], bq[1], bq[3]};
+        *(f32x4*)d = ev; *(f32x4*)(d + 4) = od;
+    };
+    auto stage_v = [&](int kt, int buf) {
+        const int key = kt * 32 + sr;
+        f32x4 a = zero4, bq = zero4;
+        if (key < curL) { const float* s = Vc + (int64_t)key * 64 + sc * 8; a = *(const f32x4*)s; bq = *(const f32x4*)(s + 4); }
+        float* d = &sV[buf][sr * VLD + sc * 8];
+        *(f32x4*)d = a; *(f32x4*)(d + 4) = bq;
+    };
+    auto scores = [&](int buf, int kt, f32x16& acc) {              // S^T tile: rows = keys, col (lane) = query
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        const float* kb = &sK[buf][r * KLD + h2 * 4];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const f32x4 kf = *(const f32x4*)(kb + c * 8);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[c * 4 + s], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h2;
+            if (key >= curL) acc[e] = -INFINITY;
+        }
+    };
+
+    // ---- pass 1: exact row max
+    float mx = -INFINITY;
+    stage_k(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < ntile; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < ntile) stage_k(kt + 1, buf ^ 1);
+        f32x16 acc;
+        scores(buf, kt, acc);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mx = fmaxf(mx, acc[e]);
+        __syncthreads();
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+
+    // ---- pass 2: p = exp(s - m), row sums, O^T += V^T . P^T
+    f32x16 o0, o1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; }
+    float lsum = 0.f;
+    stage_k(0, 0); stage_v(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < ntile; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < ntile) { stage_k(kt + 1, buf ^ 1); stage_v(kt + 1, buf ^ 1); }
+        f32x16 p;
+        scores(buf, kt, p);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) p[e] = vm_exp(p[e] - mx);
+        swap_pair<0>(p); swap_pair<2>(p); swap_pair<4>(p); swap_pair<6>(p);
+        swap_pair<8>(p); swap_pair<10>(p); swap_pair<12>(p); swap_pair<14>(p);
+        // natural key order of the registers: groups of 4 regs (4g..4g+3) hold steps 4g..4g+3 in the order {0,2,1,3}
+        const float* vb = &sV[buf][h2 * VLD + r];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = 4 * g + ((u & 1) << 1) + (u >> 1);     // u=0,1,2,3 -> reg 4g+{0,2,1,3}
+                const int s = 4 * g + u;                             // MFMA step: keys 2s, 2s+1
+                const float pv = p[e];
+                lsum = lsum + pv;
+                const float v0 = vb[(2 * s) * VLD], v1 = vb[(2 * s) * VLD + 32];
+                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, pv, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, pv, o1, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+
+    // ---- O^T accumulators: col (lane&31) = query, row = channel.  Transpose through LDS, store 256-byte rows.
+    {
+        float* st = sO[wave];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int c = (e & 3) + 8 * (e >> 2) + 4 * h2;
+            st[r * OLD + c] = o0[e] / ltot;
+            st[r * OLD + 32 + c] = o1[e] / ltot;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
+        for (int qi = 0; qi < 32; ++qi) {
+            const int t = t0 + qi;
+            if (t < l) out[((int64_t)b * l + t) * C + hd * 64 + lane] = st[qi * OLD + lane];
+        }
+    }
+}
+
+extern "C" int varhip_attn_cached_f32(const float* q, const float* kcache, const float* vcache, float* out,
+                                      int B2, int l, int H, int curL, int Lmax, varhip_stream_t stream) {
+    if (B2 <= 0 || l <= 0 || H <= 0 || curL <= 0 || curL > Lmax) return VARHIP_EINVAL;
+    if (B2 > 65535 || H > 65535) return VARHIP_EINVAL;
+    VhScope sc(VH_FAM_ATTN, (hipStream_t)stream, 4.0 * B2 * H * (double)l * curL * 64,
+               4.0 * B2 * H * (2.0 * curL * 64 + 2.0 * l * 64));
+    dim3 grid((l + 127) / 128, H, B2);
+    hipLaunchKernelGGL(k_attn_cached, grid, dim3(256), 0, (hipStream_t)stream, q, kcache, vcache, out, l, H, curL, Lmax);
+    return vh_launch_status();
+}

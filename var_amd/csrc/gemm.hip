@@ -1,0 +1,259 @@
+// gemm.hip — fp32 MFMA GEMM (out = epi(A . W^T + bias)) and implicit-GEMM 3x3 convolution for gfx950.
+//
+// Arithmetic contract: each output element is ONE k-ascending fp32 fma chain from 0 — which is exactly what a
+// sequence of v_mfma_f32_32x32x2_f32 into one accumulator computes (cdna_hip_programming.md §3 "FP32-input MFMA").
+// So no split-K and no reordering of k: the result is bit-identical to oracle/var_oracle.c.
+//
+// Tiling: 256 threads = 4 waves; a wave owns (TM*32) x (TN*32) outputs as TM*TN 32x32 accumulators (16 VGPRs each).
+// K is consumed in tiles of BK; both operands are K-contiguous ("NT"), staged global -> registers -> LDS with a
+// one-tile register prefetch and two LDS stages (one barrier per K tile).
+// LDS image of an operand tile: [rows][BK+4]; inside every 8-float chunk the even k's come first, then the odd k's:
+//   position c*8 + 0..3 = k{0,2,4,6},  c*8 + 4..7 = k{1,3,5,7}.
+// MFMA 32x32x2 takes k = lane>>5 from the lane halves, so lane (r, h) reads ONE ds_read_b128 at row r, chunk c,
+// half h and gets its operand for 4 consecutive MFMAs, which walk k = 2j+h, j=0..3, in natural ascending order.
+// Row stride BK+4 floats makes those b128 reads (and the staging b128 writes) bank-conflict free.
+#include "common.h"
+
+struct GemmP {
+    const float* A; const float* W; const float* bias; float* out; const float* resid; const float* gamma;
+    int64_t lda, ldw, ldo, ldr, ldg, sA, sW, sO;
+    int M, N, K, epi, rows_per_group, bias_per_row;
+    int H, Wd, Cin, up2, out_mode, Hi, Wi;     // convolution only
+    int tilesM, tilesN;
+};
+
+template <int TM, int TN, int WGM, int WGN, int BK, bool CONV>
+__global__ void __launch_bounds__(256) k_mfma_gemm(GemmP p) {
+    constexpr int BM = TM * 32 * WGM, BN = TN * 32 * WGN, LDSW = BK + 4, CPR = BK / 8;
+    constexpr int NA = (BM * CPR + 255) / 256, NB = (BN * CPR + 255) / 256;
+    constexpr int STAGE = (BM + BN) * LDSW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    // ---- block -> tile: XCD-contiguous remap (blocks b, b+8 share an L2), then grouped order (8 m-tiles per group)
+    int tm_, tn_;
+    {
+        const int nwg = p.tilesM * p.tilesN, bid = blockIdx.x;
+        const int q = nwg >> 3, rem = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        const int lin = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + loc;
+        const int GM = 8, width = GM * p.tilesN, group = lin / width, first = group * GM;
+        const int gsz = (p.tilesM - first) < GM ? (p.tilesM - first) : GM;
+        tm_ = first + (lin % width) % gsz;
+        tn_ = (lin % width) / gsz;
+    }
+    const int m0 = tm_ * BM, n0 = tn_ * BN;
+    const int bz = blockIdx.z;
+    const float* Ab = p.A + (int64_t)bz * p.sA;
+    const float* Wb = p.W + (int64_t)bz * p.sW;
+    float* Ob = p.out + (int64_t)bz * p.sO;
+
+    // ---- staging bookkeeping: each thread owns NA chunks of A and NB chunks of W (chunk = 8 consecutive k of one row)
+    int a_row[NA], a_c[NA]; bool a_ok[NA];
+    int a_b[NA], a_y[NA], a_x[NA];              // CONV: pixel coordinates of the row
+    const float* a_ptr[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int qq = tid + 256 * i;
+        a_row[i] = qq / CPR; a_c[i] = qq % CPR;
+        const int m = m0 + a_row[i];
+        a_ok[i] = (qq < BM * CPR) && (m < p.M);
+        if (CONV) {
+            const int hw = p.H * p.Wd;
+            const int mm = a_ok[i] ? m : 0;
+            a_b[i] = mm / hw; const int rem2 = mm % hw; a_y[i] = rem2 / p.Wd; a_x[i] = rem2 % p.Wd;
+            a_ptr[i] = Ab;
+        } else {
+            a_ptr[i] = Ab + (int64_t)(a_ok[i] ? m : 0) * p.lda + a_c[i] * 8;
+        }
+    }
+    int b_row[NB], b_c[NB]; bool b_ok[NB];
+    const float* b_ptr[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int qq = tid + 256 * i;
+        b_row[i] = qq / CPR; b_c[i] = qq % CPR;
+        const int n = n0 + b_row[i];
+        b_ok[i] = (qq < BN * CPR) && (n < p.N);
+        b_ptr[i] = Wb + (int64_t)(b_ok[i] ? n : 0) * p.ldw + b_c[i] * 8;
+    }
+
+    f32x4 ra[NA][2], rb[NB][2];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            bool ok = a_ok[i] && (k0 + a_c[i] * 8 < p.K);
+            const float* src;
+            if (CONV) {
+                const int tap = k0 / p.Cin, ci0 = k0 - tap * p.Cin;
+                const int ky = tap / 3, kx = tap - ky * 3;
+                const int yy = a_y[i] + ky - 1, xx = a_x[i] + kx - 1;
+                ok = ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd;
+                const int sy = p.up2 ? (yy >> 1) : yy, sx = p.up2 ? (xx >> 1) : xx;
+                src = Ab + (((int64_t)a_b[i] * p.Hi + (ok ? sy : 0)) * p.Wi + (ok ? sx : 0)) * p.Cin + ci0 + a_c[i] * 8;
+            } else {
+                src = a_ptr[i] + k0;
+            }
+            if (ok) { ra[i][0] = *(const f32x4*)src; ra[i][1] = *(const f32x4*)(src + 4); }
+            else { ra[i][0] = zero4; ra[i][1] = zero4; }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const bool ok = b_ok[i] && (k0 + b_c[i] * 8 < p.K);
+            const float* src = b_ptr[i] + k0;
+            if (ok) { rb[i][0] = *(const f32x4*)src; rb[i][1] = *(const f32x4*)(src + 4); }
+            else { rb[i][0] = zero4; rb[i][1] = zero4; }
+        }
+    };
+    auto store_tile = [&](int stage) {
+        float* sA = smem + stage * STAGE;
+        float* sB = sA + BM * LDSW;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            if (tid + 256 * i < BM * CPR) {
+                float* d = sA + a_row[i] * LDSW + a_c[i] * 8;
+                const f32x4 ev = {ra[i][0][0], ra[i][0][2], ra[i][1][0], ra[i][1][2]};
+                const f32x4 od = {ra[i][0][1], ra[i][0][3], ra[i][1][1], ra[i][1][3]};
+                *(f32x4*)d = ev; *(f32x4*)(d + 4) = od;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            if (tid + 256 * i < BN * CPR) {
+                float* d = sB + b_row[i] * LDSW + b_c[i] * 8;
+                const f32x4 ev = {rb[i][0][0], rb[i][0][2], rb[i][1][0], rb[i][1][2]};
+                const f32x4 od = {rb[i][0][1], rb[i][0][3], rb[i][1][1], rb[i][1][3]};
+                *(f32x4*)d = ev; *(f32x4*)(d + 4) = od;
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nk = (p.K + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const float* sA = smem + cur * STAGE + (wm * TM * 32 + r) * LDSW + h * 4;
+        const float* sB = smem + cur * STAGE + BM * LDSW + (wn * TN * 32 + r) * LDSW + h * 4;
+#pragma unroll
+        for (int c = 0; c < CPR; ++c) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *(const f32x4*)(sA + i * 32 * LDSW + c * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *(const f32x4*)(sB + j * 32 * LDSW + c * 8);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout of the 32x32 accumulator: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 32 + r;
+            if (n >= p.N) continue;
+            const float bn = (p.bias && !p.bias_per_row) ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m >= p.M) continue;
+                float v = acc[i][j][e];
+                if (p.bias) v = v + (p.bias_per_row ? p.bias[m] : bn);
+                if (p.epi == VARHIP_EPI_GELU) v = vm_gelu_tanh(v);
+                else if (p.epi == VARHIP_EPI_RESID) {
+                    if (p.gamma) v = v * p.gamma[(int64_t)(m / p.rows_per_group) * p.ldg + n];
+                    v = p.resid[(int64_t)m * p.ldr + n] + v;
+                }
+                if (CONV && p.out_mode == 1) {
+                    const int hw = p.H * p.Wd;
+                    const int b = m / hw, rem2 = m - b * hw;
+                    v = vm_min(vm_max(v, -1.0f), 1.0f);
+                    Ob[((int64_t)b * p.N + n) * hw + rem2] = (v + 1.0f) * 0.5f;
+                } else {
+                    Ob[(int64_t)m * p.ldo + n] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int TM, int TN, int WGM, int WGN, int BK, bool CONV>
+static int launch_gemm(GemmP& p, int batch, hipStream_t stream) {
+    constexpr int BM = TM * 32 * WGM, BN = TN * 32 * WGN;
+    constexpr size_t lds = 2 * (size_t)(BM + BN) * (BK + 4) * sizeof(float);
+    p.tilesM = (p.M + BM - 1) / BM; p.tilesN = (p.N + BN - 1) / BN;
+    auto kfn = k_mfma_gemm<TM, TN, WGM, WGN, BK, CONV>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (lds > 48 * 1024) hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    dim3 grid(p.tilesM * p.tilesN, 1, batch);
+    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, stream, p);
+    return vh_launch_status();
+}
+
+extern "C" int varhip_gemm_nt_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
+                                  float* out, int64_t ldo, int M, int N, int K, int epi,
+                                  const float* resid, int64_t ldr, const float* gamma, int64_t ldg, int rows_per_group,
+                                  int bias_per_row, int batch, int64_t sA, int64_t sW, int64_t sO, varhip_stream_t stream) {
+    if (M < 0 || N <= 0 || K <= 0 || batch < 1 || (K & 7) || (lda & 3) || (ldw & 3)) return VARHIP_EINVAL;
+    if (((uintptr_t)A | (uintptr_t)W) & 15) return VARHIP_EINVAL;
+    if (batch > 1 && (resid || gamma)) return VARHIP_EINVAL;
+    if (epi < 0 || epi > 2 || (epi == VARHIP_EPI_RESID && !resid)) return VARHIP_EINVAL;
+    if (M == 0) return 0;
+    GemmP p{};
+    p.A = A; p.W = W; p.bias = bias; p.out = out; p.resid = resid; p.gamma = gamma;
+    p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.ldr = ldr; p.ldg = ldg; p.sA = sA; p.sW = sW; p.sO = sO;
+    p.M = M; p.N = N; p.K = K; p.epi = epi; p.rows_per_group = rows_per_group > 0 ? rows_per_group : 1; p.bias_per_row = bias_per_row;
+    VhScope scope(VH_FAM_GEMM, (hipStream_t)stream, 2.0 * M * N * (double)K * batch,
+                  4.0 * batch * ((double)M * K + (double)N * K + (double)M * N));
+    const int64_t big_tiles = (int64_t)((M + 127) / 128) * ((N + 127) / 128) * batch;
+    if (big_tiles >= 192) return launch_gemm<2, 2, 2, 2, 32, false>(p, batch, (hipStream_t)stream);
+    return launch_gemm<1, 1, 2, 2, 32, false>(p, batch, (hipStream_t)stream);
+}
+
+extern "C" int varhip_conv3x3_nhwc_f32(const float* in, const float* w, const float* bias, const float* resid, float* out,
+                                       int B, int H, int W, int Cin, int Cout, int up2, int out_mode, varhip_stream_t stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (Cin & 15) || !bias) return VARHIP_EINVAL;
+    if (up2 && ((H & 1) || (W & 1))) return VARHIP_EINVAL;
+    if (out_mode < 0 || out_mode > 1 || (out_mode == 1 && resid)) return VARHIP_EINVAL;
+    if ((int64_t)B * H * W >= (1ll << 31)) return VARHIP_EINVAL;
+    GemmP p{};
+    p.A = in; p.W = w; p.bias = bias; p.out = out; p.resid = resid; p.gamma = nullptr;
+    p.ldw = 9ll * Cin; p.ldo = Cout; p.ldr = Cout;
+    p.M = B * H * W; p.N = Cout; p.K = 9 * Cin; p.epi = resid ? VARHIP_EPI_RESID : VARHIP_EPI_NONE; p.rows_per_group = 1;
+    p.H = H; p.Wd = W; p.Cin = Cin; p.up2 = up2; p.out_mode = out_mode; p.Hi = up2 ? H / 2 : H; p.Wi = up2 ? W / 2 : W;
+    const double npix = (double)B * H * W;
+    VhScope scope(VH_FAM_CONV, (hipStream_t)stream, 2.0 * npix * Cout * 9.0 * Cin,
+                  4.0 * (npix * Cin / (up2 ? 4.0 : 1.0) + npix * Cout * (resid ? 2.0 : 1.0) + 9.0 * Cin * Cout));
+    hipStream_t s = (hipStream_t)stream;
+    if (Cout % 160 == 0) return launch_gemm<1, 5, 4, 1, 16, true>(p, 1, s);
+    if (Cout % 128 == 0) return launch_gemm<1, 4, 4, 1, 16, true>(p, 1, s);
+    if (Cout % 64 == 0) return launch_gemm<1, 2, 4, 1, 16, true>(p, 1, s);
+    return launch_gemm<1, 1, 4, 1, 16, true>(p, 1, s);
+}

@@ -1,0 +1,139 @@
+// quant.hip — the multi-scale quantizer step between two transformer passes, and the encode-side nearest-code lookup.
+//   varhip_quant_accum_f32 : codebook gather -> bicubic up to PxP -> Phi (3x3 conv residual mix) -> f_hat +=      (quant.py:187-206)
+//   varhip_next_map_f32    : area-pool f_hat to the next scale -> word_embed + level/position embedding, x2 for CFG (var.py:185-187)
+//   varhip_nearest_code_f32: argmin_v |z - e_v|^2                                                                     (quant.py:150-157)
+// These tensors are tiny (B x 16 x 16 x 32 floats): the kernels are one-thread-per-output with sequential fma chains in
+// the oracle's order; what matters is that the whole step is 4 launches instead of the reference's ~15 ATen calls.
+#include "common.h"
+
+__global__ void k_gather_up(const int64_t* __restrict__ idx, const float* __restrict__ codebook, const int32_t* __restrict__ tap_idx,
+                            const float* __restrict__ tap_w, float* __restrict__ up, int B, int pn, int P, int Cv) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // [B][P][P][Cv]
+    if (i >= (int64_t)B * P * P * Cv) return;
+    const int c = (int)(i % Cv); int64_t t = i / Cv; const int x = (int)(t % P); t /= P; const int y = (int)(t % P); const int b = (int)(t / P);
+    const int64_t* ib = idx + (int64_t)b * pn * pn;
+    if (pn == P) { up[i] = codebook[ib[y * pn + x] * Cv + c]; return; }
+    const int32_t* iy = tap_idx + y * 4; const float* wy = tap_w + y * 4;
+    const int32_t* ix = tap_idx + x * 4; const float* wx = tap_w + x * 4;
+    float rr[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int64_t* ir = ib + iy[a] * pn;
+        float acc = codebook[ir[ix[0]] * Cv + c] * wx[0];
+        acc = vm_fma(codebook[ir[ix[1]] * Cv + c], wx[1], acc);
+        acc = vm_fma(codebook[ir[ix[2]] * Cv + c], wx[2], acc);
+        acc = vm_fma(codebook[ir[ix[3]] * Cv + c], wx[3], acc);
+        rr[a] = acc;
+    }
+    float o = rr[0] * wy[0];
+    o = vm_fma(rr[1], wy[1], o); o = vm_fma(rr[2], wy[2], o); o = vm_fma(rr[3], wy[3], o);
+    up[i] = o;
+}
+
+__global__ void k_phi_accum(const float* __restrict__ up, const float* __restrict__ phi_w, const float* __restrict__ phi_b, float ratio, float keep,
+                            float* __restrict__ f_hat, int B, int P, int Cv) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // [B][P][P][Cv] over co
+    if (i >= (int64_t)B * P * P * Cv) return;
+    const int co = (int)(i % Cv); int64_t t = i / Cv; const int x = (int)(t % P); t /= P; const int y = (int)(t % P); const int b = (int)(t / P);
+    float acc = 0.f;
+    for (int ky = 0; ky < 3; ++ky) {
+        const int yy = y + ky - 1; if (yy < 0 || yy >= P) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int xx = x + kx - 1; if (xx < 0 || xx >= P) continue;
+            const float* u = up + (((int64_t)b * P + yy) * P + xx) * Cv;
+            const float* w = phi_w + (((int64_t)co * 3 + ky) * 3 + kx) * Cv;
+            for (int ci = 0; ci < Cv; ++ci) acc = vm_fma(u[ci], w[ci], acc);
+        }
+    }
+    const float conv = acc + phi_b[co];
+    const float hmix = up[i] * keep + conv * ratio;
+    f_hat[i] = f_hat[i] + hmix;
+}
+
+extern "C" int varhip_quant_accum_f32(const int64_t* idx, const float* codebook, const int32_t* tap_idx, const float* tap_w,
+                                      const float* phi_w, const float* phi_b, float ratio, float* up, float* f_hat,
+                                      int B, int pn, int P, int Cv, varhip_stream_t stream) {
+    if (B <= 0 || pn <= 0 || P <= 0 || pn > P || Cv <= 0 || Cv > 64) return VARHIP_EINVAL;
+    if (pn != P && (!tap_idx || !tap_w)) return VARHIP_EINVAL;
+    const int64_t tot = (int64_t)B * P * P * Cv;
+    VhScope sc(VH_FAM_OTHER, (hipStream_t)stream, 2.0 * tot * 9 * Cv, 16.0 * tot);
+    const unsigned blocks = (unsigned)((tot + 255) / 256);
+    hipLaunchKernelGGL(k_gather_up, dim3(blocks), dim3(256), 0, (hipStream_t)stream, idx, codebook, tap_idx, tap_w, up, B, pn, P, Cv);
+    hipLaunchKernelGGL(k_phi_accum, dim3(blocks), dim3(256), 0, (hipStream_t)stream, up, phi_w, phi_b, ratio, 1.0f - ratio, f_hat, B, P, Cv);
+    return vh_launch_status();
+}
+
+__global__ void k_area_pool(const float* __restrict__ f_hat, float* __restrict__ pooled, int B, int P, int pq, int Cv) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // [B][pq*pq][Cv]
+    if (i >= (int64_t)B * pq * pq * Cv) return;
+    const int c = (int)(i % Cv); int64_t t = i / Cv; const int tt = (int)(t % (pq * pq)); const int b = (int)(t / (pq * pq));
+    const int oy = tt / pq, ox = tt % pq;
+    const int y0 = (oy * P) / pq, y1 = ((oy + 1) * P + pq - 1) / pq;
+    const int x0 = (ox * P) / pq, x1 = ((ox + 1) * P + pq - 1) / pq;
+    float s = 0.f;
+    for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) s = s + f_hat[(((int64_t)b * P + y) * P + x) * Cv + c];
+    pooled[i] = (s / (float)(y1 - y0)) / (float)(x1 - x0);
+}
+
+__global__ void k_word_embed(const float* __restrict__ pooled, const float* __restrict__ word_w, const float* __restrict__ word_b,
+                             const float* __restrict__ lvl_pos, float* __restrict__ x_out, int B, int lq, int C, int Cv) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // [B][lq][C]
+    if (i >= (int64_t)B * lq * C) return;
+    const int n = (int)(i % C); const int64_t bt = i / C; const int t = (int)(bt % lq);
+    const float* pl = pooled + bt * Cv;
+    const float* w = word_w + (int64_t)n * Cv;
+    float acc = 0.f;
+    for (int c = 0; c < Cv; ++c) acc = vm_fma(pl[c], w[c], acc);
+    const float v = (acc + word_b[n]) + lvl_pos[(int64_t)t * C + n];
+    x_out[i] = v;
+    x_out[i + (int64_t)B * lq * C] = v;
+}
+
+extern "C" int varhip_next_map_f32(const float* f_hat, const float* word_w, const float* word_b, const float* lvl_pos,
+                                   float* x_out, float* pooled, int B, int P, int pq, int C, int Cv, varhip_stream_t stream) {
+    if (B <= 0 || P <= 0 || pq <= 0 || pq > P || C <= 0 || Cv <= 0 || !pooled) return VARHIP_EINVAL;
+    const int lq = pq * pq;
+    VhScope sc(VH_FAM_OTHER, (hipStream_t)stream, 2.0 * B * lq * (double)C * Cv, 8.0 * B * lq * (double)C);
+    const int64_t t1 = (int64_t)B * lq * Cv, t2 = (int64_t)B * lq * C;
+    hipLaunchKernelGGL(k_area_pool, dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, f_hat, pooled, B, P, pq, Cv);
+    hipLaunchKernelGGL(k_word_embed, dim3((unsigned)((t2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pooled, word_w, word_b, lvl_pos, x_out, B, lq, C, Cv);
+    return vh_launch_status();
+}
+
+// nearest code: one workgroup per z row; thread t scores codes t, t+256, ...; (distance, index) min with first-index ties
+__global__ void __launch_bounds__(256) k_nearest_code(const float* __restrict__ z, const float* __restrict__ codebook, int64_t* __restrict__ idx_out, int V, int Cv) {
+    __shared__ float sz[64];
+    __shared__ float s_d[4]; __shared__ int s_i[4];
+    const int tid = threadIdx.x; const int64_t n = blockIdx.x;
+    if (tid < Cv) sz[tid] = z[n * Cv + tid];
+    __syncthreads();
+    float zz = 0.f;
+    for (int c = 0; c < Cv; ++c) zz = vm_fma(sz[c], sz[c], zz);
+    float bd = INFINITY; int bi = 0x7fffffff;
+    for (int v = tid; v < V; v += 256) {
+        const float* e = codebook + (int64_t)v * Cv;
+        float ee = 0.f, dot = 0.f;
+        for (int c = 0; c < Cv; ++c) { ee = vm_fma(e[c], e[c], ee); dot = vm_fma(sz[c], e[c], dot); }
+        const float d = (zz + ee) + (-2.0f * dot);
+        if (d < bd) { bd = d; bi = v; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float od = __shfl_xor(bd, off, 64); const int oi = __shfl_xor(bi, off, 64);
+        if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+    }
+    if ((tid & 63) == 0) { s_d[tid >> 6] = bd; s_i[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w) if (s_d[w] < bd || (s_d[w] == bd && s_i[w] < bi)) { bd = s_d[w]; bi = s_i[w]; }
+        idx_out[n] = bi == 0x7fffffff ? 0 : bi;
+    }
+}
+extern "C" int varhip_nearest_code_f32(const float* z, const float* codebook, int64_t* idx_out, int N, int V, int Cv, varhip_stream_t stream) {
+    if (N < 0 || V <= 0 || Cv <= 0 || Cv > 64) return VARHIP_EINVAL;
+    if (N == 0) return 0;
+    VhScope sc(VH_FAM_OTHER, (hipStream_t)stream, 4.0 * N * (double)V * Cv, 4.0 * ((double)N * Cv + (double)V * Cv));
+    hipLaunchKernelGGL(k_nearest_code, dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream, z, codebook, idx_out, V, Cv);
+    return vh_launch_status();
+}

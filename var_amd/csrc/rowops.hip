@@ -1,0 +1,310 @@
+// rowops.hip — bandwidth-bound row/elementwise kernels: SiLU, AdaLN LayerNorm+modulate, q/k/v post-processing with
+// in-place KV-cache append, GroupNorm (stats + apply), row softmax, layout copies, prologue embeddings.
+// Reductions follow the canonical orders of common.h so results are bit-identical to oracle/var_oracle.c.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void k_silu(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) y[i] = vm_silu(x[i]);
+}
+extern "C" int varhip_silu_f32(const float* x, float* y, int64_t n, varhip_stream_t stream) {
+    if (n < 0) return VARHIP_EINVAL;
+    if (n == 0) return 0;
+    VhScope sc(VH_FAM_OTHER, (hipStream_t)stream, 0, 8.0 * n);
+    int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k_silu, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, n);
+    return vh_launch_status();
+}
+
+__global__ void k_add_bcast(const float* __restrict__ base, const float* __restrict__ cond, float* __restrict__ out, int rows, int n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t tot = (int64_t)rows * n;
+    if (i < tot) out[i] = base[i % n] + cond[i];
+}
+extern "C" int varhip_add_bcast_f32(const float* base, const float* cond, float* out, int rows, int n, varhip_stream_t stream) {
+    if (rows <= 0 || n <= 0) return VARHIP_EINVAL;
+    VhScope sc(VH_FAM_OTHER, (hipStream_t)stream, 0, 8.0 * rows * n);
+    int64_t tot = (int64_t)rows * n;
+    hipLaunchKernelGGL(k_add_bcast, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, base, cond, out, rows, n);
+    return vh_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// AdaLN: one wave per row.  Lane j holds elements 256*t + 4*j + {0..3}: canonical W64(vw=4) partials.
+#define LN_MAXV 10      // C <= 2560
+__global__ void __launch_bounds__(256) k_ln_modulate(const float* __restrict__ x, const float* __restrict__ scale, int64_t lds_,
+                                                     const float* __restrict__ shift, int64_t ldh, float* __restrict__ out,
+                                                     int M, int C, int rows_per_group, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int nv = (C + 255) / 256;
+    const float* xr = x + (int64_t)m * C;
+    f32x4 v[LN_MAXV];
+    float part = 0.f;
+#pragma unroll
+    for (int t = 0; t < LN_MAXV; ++t) {
+        if (t < nv) {
+            const int i = 256 * t + 4 * lane;
+            if (i < C) { v[t] = *(const f32x4*)(xr + i); part = part + v[t][0]; part = part + v[t][1]; part = part + v[t][2]; part = part + v[t][3]; }
+            else { v[t][0] = v[t][1] = v[t][2] = v[t][3] = 0.f; }
+        }
+    }
+    const float mean = vh_wave_sum(part) / (float)C;
+    part = 0.f;
+#pragma unroll
+    for (int t = 0; t < LN_MAXV; ++t) {
+        if (t < nv) {
+            const int i = 256 * t + 4 * lane;
+            if (i < C) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[t][e] = v[t][e] - mean; part = part + v[t][e] * v[t][e]; }
+            }
+        }
+    }
+    const float var = vh_wave_sum(part) / (float)C;
+    const float rstd = 1.0f / vm_sqrt(var + eps);
+    const float* sc = scale + (int64_t)(m / rows_per_group) * lds_;
+    const float* sh = shift + (int64_t)(m / rows_per_group) * ldh;
+#pragma unroll
+    for (int t = 0; t < LN_MAXV; ++t) {
+        if (t < nv) {
+            const int i = 256 * t + 4 * lane;
+            if (i < C) {
+                const f32x4 s4 = *(const f32x4*)(sc + i), h4 = *(const f32x4*)(sh + i);
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (v[t][e] * rstd) * (s4[e] + 1.0f) + h4[e];
+                *(f32x4*)(out + (int64_t)m * C + i) = o;
+            }
+        }
+    }
+}
+extern "C" int varhip_ln_modulate_f32(const float* x, const float* scale, int64_t ld_scale, const float* shift, int64_t ld_shift,
+                                      float* out, int M, int C, int rows_per_group, float eps, varhip_stream_t stream) {
+    if (M < 0 || C <= 0 || (C & 3) || C > 256 * LN_MAXV || rows_per_group <= 0 || (ld_scale & 3) || (ld_shift & 3)) return VARHIP_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)scale | (uintptr_t)shift | (uintptr_t)out) & 15) return VARHIP_EINVAL;
+    if (M == 0) return 0;
+    VhScope sc(VH_FAM_LN, (hipStream_t)stream, 8.0 * M * C, 8.0 * M * C);
+    hipLaunchKernelGGL(k_ln_modulate, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, scale, ld_scale, shift, ld_shift, out, M, C, rows_per_group, eps);
+    return vh_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// q/k/v post-processing: one wave per (row, head), lane = channel (head_dim 64).
+__global__ void __launch_bounds__(256) k_qkv_prep(const float* __restrict__ qkv, const float* __restrict__ scale_mul, float plain_scale, int l2norm,
+                                                  float* __restrict__ q_out, float* __restrict__ kcache, float* __restrict__ vcache,
+                                                  int B2, int l, int H, int pos0, int Lmax) {
+    const int lane = threadIdx.x & 63;
+    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);       // (row, head)
+    const int64_t rows = (int64_t)B2 * l;
+    if (item >= rows * H) return;
+    const int64_t row = item / H; const int h = (int)(item - row * H);
+    const int b = (int)(row / l), t = (int)(row - (int64_t)b * l);
+    const int C = H * 64;
+    const float* src = qkv + row * 3 * C + h * 64 + lane;
+    float q = src[0], k = src[C], v = src[2 * C];
+    if (l2norm) {
+        const float dq = vm_max(vm_sqrt(vh_wave_sum(q * q)), 1e-12f);
+        const float dk = vm_max(vm_sqrt(vh_wave_sum(k * k)), 1e-12f);
+        const float sm = vm_exp(vm_min(scale_mul[h], 4.605170249938965f));
+        q = (q / dq) * sm;
+        k = k / dk;
+    } else {
+        q = q * plain_scale;
+    }
+    q_out[row * C + h * 64 + lane] = q;
+    const int64_t co = (((int64_t)b * H + h) * Lmax + pos0 + t) * 64 + lane;
+    kcache[co] = k; vcache[co] = v;
+}
+extern "C" int varhip_qkv_prep_f32(const float* qkv, const float* scale_mul, float plain_scale, int l2norm,
+                                   float* q_out, float* kcache, float* vcache, int B2, int l, int H, int pos0, int Lmax, varhip_stream_t stream) {
+    if (B2 <= 0 || l <= 0 || H <= 0 || pos0 < 0 || pos0 + l > Lmax || (l2norm && !scale_mul)) return VARHIP_EINVAL;
+    const int64_t items = (int64_t)B2 * l * H;
+    VhScope sc(VH_FAM_QKV, (hipStream_t)stream, 0, 4.0 * items * 64 * 6);
+    hipLaunchKernelGGL(k_qkv_prep, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, (hipStream_t)stream, qkv, scale_mul, plain_scale, l2norm,
+                       q_out, kcache, vcache, B2, l, H, pos0, Lmax);
+    return vh_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// row softmax (VAE attention, n = HW): one wave per row, lane j holds i = j, j+64, ...: canonical W64(vw=1).
+#define SM_MAXE 16      // n <= 1024
+__global__ void __launch_bounds__(256) k_softmax_rows(const float* __restrict__ x, float* __restrict__ out, int64_t rows, int n, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float e[SM_MAXE];
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < SM_MAXE; ++t) {
+        const int i = lane + 64 * t;
+        if (i < n) { e[t] = x[r * n + i] * scale; m = fmaxf(m, e[t]); }
+    }
+    m = vh_wave_max(m);
+    float part = 0.f;
+#pragma unroll
+    for (int t = 0; t < SM_MAXE; ++t) {
+        const int i = lane + 64 * t;
+        if (i < n) { e[t] = vm_exp(e[t] - m); part = part + e[t]; }
+    }
+    const float S = vh_wave_sum(part);
+#pragma unroll
+    for (int t = 0; t < SM_MAXE; ++t) {
+        const int i = lane + 64 * t;
+        if (i < n) out[r * n + i] = e[t] / S;
+    }
+}
+extern "C" int varhip_softmax_rows_f32(const float* x, float* out, int64_t rows, int n, float scale, varhip_stream_t stream) {
+    if (rows < 0 || n <= 0 || n > 64 * SM_MAXE) return VARHIP_EINVAL;
+    if (rows == 0) return 0;
+    VhScope sc(VH_FAM_OTHER, (hipStream_t)stream, 0, 8.0 * rows * n);
+    hipLaunchKernelGGL(k_softmax_rows, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, out, rows, n, scale);
+    return vh_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// GroupNorm statistics.  Pass 1: block = (chunk of GN_PIX pixels, sample): per-channel fp64 sum / sum of squares over the
+// chunk, folded to groups -> scratch[b][chunk][g][2].  Pass 2: per (b,g) sum the chunks in order, mean / rstd.
+#define GN_PIX 256
+__global__ void __launch_bounds__(256) k_gn_partial(const float* __restrict__ x, double* __restrict__ scratch, int HW, int C, int G, int nchunk) {
+    extern __shared__ double gsm[];                 // [2][C]
+    const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int p0 = chunk * GN_PIX, p1 = (p0 + GN_PIX < HW) ? p0 + GN_PIX : HW;
+    for (int c = tid; c < C; c += 256) {
+        double s = 0.0, s2 = 0.0;
+        const float* px = x + ((int64_t)b * HW + p0) * C + c;
+        for (int p = p0; p < p1; ++p, px += C) { const double v = (double)*px; s += v; s2 += v * v; }
+        gsm[c] = s; gsm[C + c] = s2;
+    }
+    __syncthreads();
+    const int cpg = C / G;
+    for (int g = tid; g < G; g += 256) {
+        double s = 0.0, s2 = 0.0;
+        for (int c = 0; c < cpg; ++c) { s += gsm[g * cpg + c]; s2 += gsm[C + g * cpg + c]; }
+        double* o = scratch + (((int64_t)b * nchunk + chunk) * G + g) * 2;
+        o[0] = s; o[1] = s2;
+    }
+}
+__global__ void k_gn_final(const double* __restrict__ scratch, float* __restrict__ stats, int B, int G, int nchunk, double count, float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * G) return;
+    const int b = i / G, g = i - b * G;
+    double s = 0.0, s2 = 0.0;
+    for (int c = 0; c < nchunk; ++c) { const double* o = scratch + (((int64_t)b * nchunk + c) * G + g) * 2; s += o[0]; s2 += o[1]; }
+    const double mean = s / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[2 * i] = (float)mean;
+    stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+extern "C" int64_t varhip_gn_scratch_elems(int B, int HW, int C, int G) {
+    (void)C;
+    return (int64_t)B * ((HW + GN_PIX - 1) / GN_PIX) * G * 2;
+}
+extern "C" int varhip_gn_stats_f32(const float* x, float* stats, double* scratch, int B, int HW, int C, int G, float eps, varhip_stream_t stream) {
+    if (B <= 0 || HW <= 0 || C <= 0 || G <= 0 || (C % G) || !scratch || C > 4096) return VARHIP_EINVAL;
+    const int nchunk = (HW + GN_PIX - 1) / GN_PIX;
+    VhScope sc(VH_FAM_GN, (hipStream_t)stream, 0, 4.0 * B * (double)HW * C);
+    hipLaunchKernelGGL(k_gn_partial, dim3(nchunk, B), dim3(256), 2 * C * sizeof(double), (hipStream_t)stream, x, scratch, HW, C, G, nchunk);
+    hipLaunchKernelGGL(k_gn_final, dim3((B * G + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch, stats, B, G, nchunk, (double)HW * (C / G), eps);
+    return vh_launch_status();
+}
+
+__global__ void __launch_bounds__(256) k_gn_apply(const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, float* __restrict__ out, int64_t n4, int HW, int C, int G, int silu) {
+    const int cpg = C / G;
+    const int64_t per_b = (int64_t)HW * C;
+    int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i4 < n4; i4 += stride) {
+        const int64_t i = i4 * 4;
+        const int b = (int)(i / per_b), c0 = (int)(i % C);
+        const f32x4 v = *(const f32x4*)(x + i);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = c0 + e;
+            const float* st = stats + ((int64_t)b * G + c / cpg) * 2;
+            float y = ((v[e] - st[0]) * st[1]) * gamma[c] + beta[c];
+            o[e] = silu ? vm_silu(y) : y;
+        }
+        *(f32x4*)(out + i) = o;
+    }
+}
+extern "C" int varhip_gn_apply_f32(const float* x, const float* stats, const float* gamma, const float* beta, float* out,
+                                   int B, int HW, int C, int G, int silu, varhip_stream_t stream) {
+    if (B <= 0 || HW <= 0 || C <= 0 || G <= 0 || (C % G) || (C & 3)) return VARHIP_EINVAL;
+    const int64_t n4 = (int64_t)B * HW * C / 4;
+    VhScope sc(VH_FAM_GN, (hipStream_t)stream, 0, 8.0 * n4 * 4);
+    int64_t blocks = (n4 + 255) / 256; if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_gn_apply, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, stats, gamma, beta, out, n4, HW, C, G, silu);
+    return vh_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void k_nchw_to_nhwc(const float* __restrict__ in, float* __restrict__ out, int C, int HW, int64_t tot) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // index into out [B][HW][C]
+    if (i >= tot) return;
+    const int c = (int)(i % C); const int64_t bp = i / C; const int p = (int)(bp % HW); const int64_t b = bp / HW;
+    out[i] = in[(b * C + c) * HW + p];
+}
+__global__ void k_nhwc_to_nchw(const float* __restrict__ in, float* __restrict__ out, int C, int HW, int64_t tot) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // index into out [B][C][HW]
+    if (i >= tot) return;
+    const int p = (int)(i % HW); const int64_t bc = i / HW; const int c = (int)(bc % C); const int64_t b = bc / C;
+    out[i] = in[(b * HW + p) * C + c];
+}
+extern "C" int varhip_nchw_to_nhwc_f32(const float* in, float* out, int B, int C, int HW, varhip_stream_t stream) {
+    if (B <= 0 || C <= 0 || HW <= 0) return VARHIP_EINVAL;
+    const int64_t tot = (int64_t)B * C * HW;
+    VhScope sc(VH_FAM_OTHER, (hipStream_t)stream, 0, 8.0 * tot);
+    hipLaunchKernelGGL(k_nchw_to_nhwc, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out, C, HW, tot);
+    return vh_launch_status();
+}
+extern "C" int varhip_nhwc_to_nchw_f32(const float* in, float* out, int B, int C, int HW, varhip_stream_t stream) {
+    if (B <= 0 || C <= 0 || HW <= 0) return VARHIP_EINVAL;
+    const int64_t tot = (int64_t)B * C * HW;
+    VhScope sc(VH_FAM_OTHER, (hipStream_t)stream, 0, 8.0 * tot);
+    hipLaunchKernelGGL(k_nhwc_to_nchw, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out, C, HW, tot);
+    return vh_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void k_lvl_pos(const float* __restrict__ lvl_embed, const int64_t* __restrict__ lvl, const float* __restrict__ pos,
+                          float* __restrict__ out, int L, int C) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)L * C) return;
+    const int t = (int)(i / C), n = (int)(i - (int64_t)t * C);
+    out[i] = lvl_embed[lvl[t] * C + n] + pos[i];
+}
+extern "C" int varhip_lvl_pos_f32(const float* lvl_embed, const int64_t* lvl, const float* pos, float* out, int L, int C, varhip_stream_t stream) {
+    if (L <= 0 || C <= 0) return VARHIP_EINVAL;
+    VhScope sc(VH_FAM_OTHER, (hipStream_t)stream, 0, 12.0 * L * C);
+    hipLaunchKernelGGL(k_lvl_pos, dim3((unsigned)(((int64_t)L * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, lvl_embed, lvl, pos, out, L, C);
+    return vh_launch_status();
+}
+
+__global__ void k_first_map(const float* __restrict__ class_emb, const int64_t* __restrict__ labels, int num_classes,
+                            const float* __restrict__ pos_start, const float* __restrict__ lvl_pos, float* __restrict__ cond,
+                            float* __restrict__ x_out, int B, int C, int first_l) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // over [2B][C]
+    if (i >= (int64_t)2 * B * C) return;
+    const int b2 = (int)(i / C), n = (int)(i - (int64_t)b2 * C);
+    int64_t cls = b2 < B ? labels[b2] : num_classes;
+    if (cls < 0 || cls > num_classes) cls = num_classes;                    // host validates; stay in bounds regardless
+    const float cv = class_emb[cls * C + n];
+    cond[i] = cv;
+    for (int t = 0; t < first_l; ++t)
+        x_out[((int64_t)b2 * first_l + t) * C + n] = (cv + pos_start[(int64_t)t * C + n]) + lvl_pos[(int64_t)t * C + n];
+}
+extern "C" int varhip_first_map_f32(const float* class_emb, const int64_t* labels, int num_classes, const float* pos_start,
+                                    const float* lvl_pos, float* cond, float* x_out, int B, int C, int first_l, varhip_stream_t stream) {
+    if (B <= 0 || C <= 0 || first_l <= 0 || num_classes < 0) return VARHIP_EINVAL;
+    VhScope sc(VH_FAM_OTHER, (hipStream_t)stream, 0, 16.0 * B * C);
+    hipLaunchKernelGGL(k_first_map, dim3((unsigned)(((int64_t)2 * B * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       class_emb, labels, num_classes, pos_start, lvl_pos, cond, x_out, B, C, first_l);
+    return vh_launch_status();
+}

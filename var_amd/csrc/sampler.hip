@@ -1,0 +1,154 @@
+// sampler.hip — classifier-free guidance + top-k + top-p + multinomial(1) in one launch, one 256-thread workgroup per
+// (image, token) row of V logits.  Replaces var.py:172-175 + helpers.py:6-19 (≈6 ATen launches, a full sort and a
+// cumsum over every row) and consumes the same Exp(1) noise tensor torch.multinomial would draw.
+//
+// Integer-exact by construction: top-k is a radix select on the monotone integer image of the floats, the top-p cut
+// walks the stable ascending order (bitonic sort of (key,index) pairs, only over the entries that survived top-k)
+// with the fp64 running sum ATen's cumsum uses, and the two softmax denominators use the canonical W256 sum.
+#include "common.h"
+
+__device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int src) {
+    return ((unsigned long long)__shfl((unsigned)(v >> 32), src, 64) << 32) | (unsigned)__shfl((unsigned)v, src, 64);
+}
+
+__global__ void __launch_bounds__(256) k_cfg_sample(const float* __restrict__ logits, const float* __restrict__ noise, int64_t* __restrict__ idx_out,
+                                                    float* __restrict__ masked_out, int64_t rows, int V, float ca, float cb,
+                                                    int top_k, int use_top_p, float thr) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm_raw[];
+    float* xs = reinterpret_cast<float*>(sm_raw);                                   // [V] working logits
+    unsigned long long* srt = reinterpret_cast<unsigned long long*>(sm_raw + sizeof(float) * V);   // [V] (key<<32 | idx)
+    __shared__ unsigned hist[256];
+    __shared__ float red[4];
+    __shared__ unsigned s_prefix, s_k, s_cnt;
+    __shared__ float s_bv[4]; __shared__ int s_bi[4]; __shared__ int s_bn[4];
+
+    const int tid = threadIdx.x;
+    const int64_t row = blockIdx.x;
+    const float* lc = logits + row * V;
+    const float* lu = logits + (rows + row) * V;
+
+    // (1) CFG combine: (1+t)*cond - t*uncond, three roundings as in the reference's tensor expression
+    for (int i = tid; i < V; i += 256) { const float a = ca * lc[i]; const float b = cb * lu[i]; xs[i] = a - b; }
+    __syncthreads();
+
+    // (2) top-k: find the key of the k-th largest by 4 rounds of 8-bit radix select from the top byte down
+    if (top_k > 0) {
+        if (tid == 0) { s_prefix = 0u; s_k = (unsigned)top_k; }
+        unsigned mask = 0u;
+        for (int pass = 3; pass >= 0; --pass) {
+            hist[tid] = 0u;
+            __syncthreads();
+            const unsigned prefix = s_prefix;
+            for (int i = tid; i < V; i += 256) {
+                const unsigned key = vm_float_key(xs[i]);
+                if ((key & mask) == prefix) atomicAdd(&hist[(key >> (8 * pass)) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned k = s_k, bin = 255u;
+                for (;; --bin) { const unsigned c = hist[bin]; if (c >= k || bin == 0u) break; k -= c; }
+                s_k = k; s_prefix = prefix | (bin << (8 * pass));
+            }
+            mask |= 255u << (8 * pass);
+            __syncthreads();
+        }
+        const unsigned kth = s_prefix;
+        for (int i = tid; i < V; i += 256) if (vm_float_key(xs[i]) < kth) xs[i] = -INFINITY;
+        __syncthreads();
+    }
+
+    // row max (exact in any order)
+    float m = -INFINITY;
+    for (int i = tid; i < V; i += 256) m = fmaxf(m, xs[i]);
+    m = vh_block_max256(m, red);
+
+    // (3) top-p
+    if (use_top_p) {
+        float part = 0.f;
+        for (int i = tid; i < V; i += 256) part = part + vm_exp(xs[i] - m);
+        const float S = vh_block_sum256(part, red);
+        // compact the finite entries (order irrelevant: they get sorted), pad to a power of two with +max keys
+        if (tid == 0) s_cnt = 0u;
+        __syncthreads();
+        for (int i = tid; i < V; i += 256) {
+            const float v = xs[i];
+            if (v > -INFINITY) { const unsigned pos = atomicAdd(&s_cnt, 1u); srt[pos] = ((unsigned long long)vm_float_key(v) << 32) | (unsigned)i; }
+        }
+        __syncthreads();
+        const int cnt = (int)s_cnt;
+        int n2 = 2; while (n2 < cnt) n2 <<= 1;
+        for (int i = cnt + tid; i < n2; i += 256) srt[i] = ~0ull;
+        __syncthreads();
+        for (int k = 2; k <= n2; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < n2; i += 256) {
+                    const int ixj = i ^ j;
+                    if (ixj > i) {
+                        const unsigned long long a = srt[i], b = srt[ixj];
+                        const bool up = (i & k) == 0;
+                        if ((a > b) == up) { srt[i] = b; srt[ixj] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        // ascending walk with the fp64 running sum; masked (-inf) entries precede everything and add exactly 0.
+        // The removed set is a prefix of the order (cum is non-decreasing); the last (largest) entry is never removed.
+        if (tid == 0) {
+            double c = 0.0;
+            for (int s = 0; s < cnt - 1; ++s) {
+                const int i = (int)(unsigned)srt[s];
+                c += (double)(vm_exp(xs[i] - m) / S);
+                if ((float)c <= thr) xs[i] = -INFINITY; else break;
+            }
+        }
+        __syncthreads();
+    }
+
+    // (4) softmax of what is left, divide by the Exp(1) noise, arg-max (first max; NaN wins, as torch.argmax)
+    float part = 0.f;
+    for (int i = tid; i < V; i += 256) part = part + vm_exp(xs[i] - m);
+    const float S = vh_block_sum256(part, red);
+    const float* qn = noise + row * V;
+    float bv = 0.f; int bi = -1; int bn = 0;
+    for (int i = tid; i < V; i += 256) {
+        const float rv = (vm_exp(xs[i] - m) / S) / qn[i];
+        const int isn = (rv != rv);
+        if (bi < 0) { bv = rv; bi = i; bn = isn; }
+        else if (!bn && (isn || rv > bv)) { bv = rv; bi = i; bn = isn; }
+    }
+    // combine across threads: NaN beats number; larger beats smaller; ties -> smaller index
+    auto better = [](float av, int ai, int an, float cv, int ci, int cn) -> bool {      // is (c) better than (a)?
+        if (ci < 0) return false;
+        if (ai < 0) return true;
+        if (an != cn) return cn != 0;
+        if (an) return ci < ai;
+        if (cv != av) return cv > av;
+        return ci < ai;
+    };
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ov = __shfl_xor(bv, off, 64); const int oi = __shfl_xor(bi, off, 64); const int on = __shfl_xor(bn, off, 64);
+        if (better(bv, bi, bn, ov, oi, on)) { bv = ov; bi = oi; bn = on; }
+    }
+    if ((tid & 63) == 0) { s_bv[tid >> 6] = bv; s_bi[tid >> 6] = bi; s_bn[tid >> 6] = bn; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w) if (better(bv, bi, bn, s_bv[w], s_bi[w], s_bn[w])) { bv = s_bv[w]; bi = s_bi[w]; bn = s_bn[w]; }
+        idx_out[row] = bi;
+    }
+    if (masked_out) for (int i = tid; i < V; i += 256) masked_out[row * V + i] = xs[i];
+}
+
+extern "C" int varhip_cfg_sample_f32(const float* logits, const float* noise, int64_t* idx_out, float* masked_out,
+                                     int B, int l, int V, double t_cfg, int top_k, double top_p, varhip_stream_t stream) {
+    if (B <= 0 || l <= 0 || V <= 0 || (V & 255) || V > 8192 || top_k < 0 || top_k > V) return VARHIP_EINVAL;
+    const int64_t rows = (int64_t)B * l;
+    const size_t lds = (sizeof(float) + sizeof(unsigned long long)) * (size_t)V;
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)k_cfg_sample, hipFuncAttributeMaxDynamicSharedMemorySize, 12 * 8192); attr_done = true; }
+    VhScope sc(VH_FAM_SAMPLER, (hipStream_t)stream, 0, 4.0 * rows * V * 3.0);
+    hipLaunchKernelGGL(k_cfg_sample, dim3((unsigned)rows), dim3(256), lds, (hipStream_t)stream, logits, noise, idx_out, masked_out, rows, V,
+                       (float)(1.0 + t_cfg), (float)t_cfg, top_k, top_p > 0.0 ? 1 : 0, (float)(1.0 - top_p));
+    return vh_launch_status();
+}

@@ -1,0 +1,77 @@
+// timing.hip — per-kernel-family HIP-event timing for bench.py's roofline leg, and the version string.
+#include "common.h"
+#include <mutex>
+#include <vector>
+
+namespace {
+struct Rec { hipEvent_t a, b; int fam; };
+std::mutex g_mu;
+int g_on = 0;
+std::vector<Rec> g_pool;          // created lazily, reused
+size_t g_used = 0;
+double g_ms[VARHIP_NFAM], g_flops[VARHIP_NFAM], g_bytes[VARHIP_NFAM];
+int64_t g_n[VARHIP_NFAM];
+const size_t kMaxRecs = 1 << 15;
+
+void drain_locked() {
+    for (size_t i = 0; i < g_used; ++i) {
+        float ms = 0.f;
+        if (hipEventSynchronize(g_pool[i].b) == hipSuccess && hipEventElapsedTime(&ms, g_pool[i].a, g_pool[i].b) == hipSuccess)
+            g_ms[g_pool[i].fam] += ms;
+    }
+    g_used = 0;
+}
+}  // namespace
+
+int vh_timing_on() { return g_on; }
+
+void vh_timing_begin(int fam, hipStream_t s, double flops, double bytes) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_used == kMaxRecs) drain_locked();
+    if (g_used == g_pool.size()) {
+        Rec r; r.fam = fam;
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+        g_pool.push_back(r);
+    }
+    g_pool[g_used].fam = fam;
+    hipEventRecord(g_pool[g_used].a, s);
+    g_flops[fam] += flops; g_bytes[fam] += bytes; g_n[fam] += 1;
+}
+
+void vh_timing_end(int fam, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    (void)fam;
+    if (g_used < g_pool.size()) { hipEventRecord(g_pool[g_used].b, s); ++g_used; }
+}
+
+extern "C" {
+
+const char* varhip_version(void) { return "var_hip 0.1.0 gfx950"; }
+
+int varhip_timing_enable(int on) { std::lock_guard<std::mutex> lk(g_mu); g_on = on ? 1 : 0; return 0; }
+
+int varhip_timing_reset(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    drain_locked();
+    for (int i = 0; i < VARHIP_NFAM; ++i) { g_ms[i] = g_flops[i] = g_bytes[i] = 0.0; g_n[i] = 0; }
+    return 0;
+}
+
+int varhip_timing_read(double* ms, double* flops, double* bytes, int64_t* launches) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    drain_locked();
+    for (int i = 0; i < VARHIP_NFAM; ++i) {
+        if (ms) ms[i] = g_ms[i];
+        if (flops) flops[i] = g_flops[i];
+        if (bytes) bytes[i] = g_bytes[i];
+        if (launches) launches[i] = g_n[i];
+    }
+    return VARHIP_NFAM;
+}
+
+const char* varhip_timing_name(int f) {
+    static const char* names[VARHIP_NFAM] = {"gemm", "conv3x3", "attn", "sampler", "ln", "qkv_prep", "gn", "other"};
+    return (f >= 0 && f < VARHIP_NFAM) ? names[f] : "?";
+}
+
+}  // extern "C"
