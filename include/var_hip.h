@@ -124,7 +124,8 @@ int varhip_first_map_f32(const float* class_emb, const int64_t* labels, int num_
  *   up2 != 0: `in` is [B][H/2][W/2][Cin] and is read through a nearest-neighbour 2x upsampling
  *             (basic_vae.py:27-28 Upsample2x: F.interpolate(scale 2,'nearest') then conv)
  *   out_mode 0: out is [B][H][W][Cout];  out_mode 1: out is [B][Cout][H][W] and holds (clamp(v,-1,1)+1)*0.5
- *             (vqvae.py:63 clamp_ and var.py:190 add_(1).mul_(0.5) fused into the last conv)
+ *             (vqvae.py:63 clamp_ and var.py:190 add_(1).mul_(0.5) fused into the last conv);
+ *   out_mode 2: [B][Cout][H][W] holding clamp(v,-1,1) only (VQVAE.fhat_to_img's own contract)
  * replaces every Conv2d(k=3) of basic_vae.py (ResnetBlock :48,:51; conv_in :180; conv_out :208; Upsample2x :25)
  * and vqvae.py:49 post_quant_conv.   Constraint: Cin % 16 == 0. */
 int varhip_conv3x3_nhwc_f32(const float* in, const float* w, const float* bias, const float* resid, float* out,

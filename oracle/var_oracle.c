@@ -436,9 +436,9 @@ static void conv3x3_core(const float* in, const float* wt, const float* bias, co
                 for (int co = 0; co < Cout; ++co) {
                     float v = acc[co] + bias[co];
                     if (resid) v = v + resid[(((int64_t)b * H + y) * W + x) * Cout + co];
-                    if (out_mode == 1) {
+                    if (out_mode != 0) {
                         v = vm_min(vm_max(v, -1.0f), 1.0f);                       /* vqvae.py:63 clamp_(-1,1) */
-                        out[(((int64_t)b * Cout + co) * H + y) * W + x] = (v + 1.0f) * 0.5f;   /* var.py:190 add_(1).mul_(0.5) */
+                        out[(((int64_t)b * Cout + co) * H + y) * W + x] = out_mode == 1 ? (v + 1.0f) * 0.5f : v;   /* var.py:190 add_(1).mul_(0.5) */
                     } else out[(((int64_t)b * H + y) * W + x) * Cout + co] = v;
                 }
             }
@@ -449,6 +449,7 @@ static void conv3x3_core(const float* in, const float* wt, const float* bias, co
 int varref_conv3x3_nhwc_f32(const float* in, const float* w, const float* bias, const float* resid, float* out,
                             int B, int H, int W, int Cin, int Cout, int up2, int out_mode) {
     if (up2 && ((H & 1) || (W & 1))) return VARHIP_EINVAL;
+    if (out_mode < 0 || out_mode > 2 || (out_mode != 0 && resid)) return VARHIP_EINVAL;
     float* wt = (float*)malloc(sizeof(float) * 9 * (size_t)Cin * Cout);     /* [Cout][3][3][Cin] -> [3][3][Cin][Cout] */
     for (int co = 0; co < Cout; ++co)
         for (int t = 0; t < 9; ++t)

@@ -1,0 +1,182 @@
+"""End-to-end parity of the HIP sampling path on a real MI355X, through the drop-in `models` API.
+
+Three comparisons per case:
+  (a) HIP vs CPU oracle on the same weights/noise: tokens, per-scale logits, f_hat and next-scale maps BIT-EXACT
+      (free-running: the loop feeds its own tokens back, so one differing bit anywhere would show up as a token flip),
+      decoded pixels within 1e-5 (GroupNorm statistics are accumulated in a different fp64 order);
+  (b) HIP vs the reference itself (golden fixtures from tools/gen_golden.py): token ids identical, image within 1e-3
+      (north_star tolerance), logits to fp32 rounding noise;
+  (c) size-independent properties at sizes the oracle cannot reach in seconds (determinism, batch-slice invariance,
+      incremental f_hat == non-incremental embed_to_fhat, image range).
+The Exp(1) noise is the reference's own stream: regenerated with a CPU torch.Generator and verified against the fixture.
+"""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+
+TINY = ['t_pn123_base', 't_pn12345', 't_nol2', 't_saln', 't_greedy', 't_nofilter', 't_b3_pn1234']
+_MODELS = {}
+
+
+def build_models(meta):
+    """our nn.Modules on the GPU with the deterministic weights of var_amd.detinit (same as the fixtures' reference run)"""
+    key = (meta['depth'], meta['ch'], tuple(meta['patch_nums']), meta['attn_l2_norm'], meta['shared_aln'])
+    if key in _MODELS:
+        return _MODELS[key]
+    from models import build_vae_var
+    from var_amd.detinit import fill_module_
+    _MODELS.clear(); torch.cuda.empty_cache()
+    with contextlib.redirect_stdout(io.StringIO()):
+        vae, var = build_vae_var(device='cuda', patch_nums=tuple(meta['patch_nums']), depth=meta['depth'], ch=meta['ch'],
+                                 shared_aln=meta['shared_aln'], attn_l2_norm=meta['attn_l2_norm'])
+    fill_module_(var, meta['depth'], 0, 'var.'); fill_module_(vae, meta['depth'], 0, 'vae.')
+    _MODELS[key] = (vae.eval(), var.eval())
+    return _MODELS[key]
+
+
+def hip_run(meta, z, force=None):
+    vae, var = build_models(meta)
+    noise = [torch.from_numpy(n) for n in util.regen_noise(meta, z)]
+    labels = torch.tensor(meta['labels'], dtype=torch.int64, device='cuda')
+    img = var.engine().sample(len(meta['labels']), labels, None, meta['cfg'], meta['top_k'], meta['top_p'], noises=noise,
+                              force_idx=None if force is None else torch.from_numpy(force.astype(np.int64)), trace=True)
+    torch.cuda.synchronize()
+    tr = var.engine().last_trace
+    return img.cpu().numpy(), {k: [t.cpu().numpy() for t in v] for k, v in tr.items()}
+
+
+def oracle_run(meta, z, force=None):
+    util.ensure_oracle_built()
+    from oracle.var_oracle import OracleVAR
+    var_sd, vae_sd = util.make_weights(meta)
+    orc = OracleVAR(var_sd, vae_sd, meta['patch_nums'], meta['depth'], attn_l2_norm=meta['attn_l2_norm'], shared_aln=meta['shared_aln'])
+    return orc.run(meta['labels'], util.regen_noise(meta, z), meta['cfg'], meta['top_k'], meta['top_p'],
+                   force_idx=None if force is None else force.astype(np.int64))
+
+
+def _compare(name, with_oracle=True, logit_atol=2e-4):
+    z, meta = util.load_case(name)
+    pns = meta['patch_nums']
+    img, tr = hip_run(meta, z)
+    msgs, ok_all = [], True
+
+    def rec(ok, m):
+        nonlocal ok_all
+        ok_all &= ok; msgs.append(('ok   ' if ok else 'FAIL ') + m)
+    idx = np.concatenate(tr['idx'], axis=1)
+    # (b) against the reference's fixture
+    rec(*util.diff_report(f'{name} tokens vs reference', idx.astype(np.int32), z['idx']))
+    rec(*util.diff_report(f'{name} image vs reference', img, z['img'], atol=1e-3))
+    for si, pn in enumerate(pns):
+        got = tr['logits'][si] if meta['full_logits'] else tr['logits'][si][:, sorted({0, pn * pn - 1}), :]
+        rec(*util.diff_report(f'{name} logits s{si} vs reference', got, z[f'logits_s{si}'], atol=logit_atol, rtol=1e-5))
+        rec(*util.diff_report(f'{name} f_hat s{si} vs reference', tr['f_hat'][si], z[f'f_hat_s{si}'], atol=2e-5, rtol=1e-5))
+    # (a) against the oracle: bit-exact
+    if with_oracle:
+        r = oracle_run(meta, z)
+        rec(*util.diff_report(f'{name} tokens vs oracle (free-running)', idx, r['idx']))
+        for si in range(len(pns)):
+            rec(*util.diff_report(f'{name} logits s{si} vs oracle (exact)', tr['logits'][si], r['logits'][si]))
+            rec(*util.diff_report(f'{name} f_hat s{si} vs oracle (exact)', tr['f_hat'][si], r['f_hat'][si]))
+            if si < len(pns) - 1:
+                rec(*util.diff_report(f'{name} next map s{si} vs oracle (exact)', tr['pooled'][si], r['pooled'][si]))
+        rec(*util.diff_report(f'{name} image vs oracle', img, r['img'], atol=1e-5))
+    print('\n'.join(msgs))
+    assert ok_all, '\n'.join(m for m in msgs if m.startswith('FAIL'))
+
+
+@pytest.mark.parametrize('name', TINY)
+def test_tiny_cases(name):
+    _compare(name)
+
+
+def test_baseline_config1_d16_pn123():
+    """BASELINE.json configs[0]: VAR-d16, patch_nums=(1,2,3), B=2 — vs reference fixture and vs oracle"""
+    _compare('d16_pn123', logit_atol=5e-4)
+
+
+def test_d16_full_pyramid_vs_reference():
+    """VAR-d16, 10 scales, 256x256, B=2: 680 token ids per image identical to the reference run; image within 1e-3"""
+    _compare('d16_full', with_oracle=False, logit_atol=1e-3)
+
+
+def test_public_api_and_properties():
+    """VAR.autoregressive_infer_cfg with the device generator: determinism, output contract, and batch-slice invariance
+    under injected noise (images are independent: SURVEY.md §8e), on the d16 (1,2,3) model."""
+    z, meta = util.load_case('d16_pn123')
+    vae, var = build_models(meta)
+    B = 5
+    labels = torch.tensor([1, 22, 333, 980, 1000], device='cuda')           # 1000 == num_classes: the unconditional class is a legal label
+    with torch.inference_mode():
+        a = var.autoregressive_infer_cfg(B, labels, g_seed=7, cfg=1.5, top_k=900, top_p=0.96)
+        b = var.autoregressive_infer_cfg(B, labels, g_seed=7, cfg=1.5, top_k=900, top_p=0.96)
+        c = var.autoregressive_infer_cfg(B, labels, g_seed=8, cfg=1.5, top_k=900, top_p=0.96)
+        d = var.autoregressive_infer_cfg(2, 7, g_seed=1, cfg=4.0, top_k=0, top_p=0.0)               # int label form
+    assert a.shape == (B, 3, 48, 48) and a.dtype == torch.float32 and d.shape == (2, 3, 48, 48)
+    assert torch.equal(a, b), 'same g_seed must reproduce bit-identical images'
+    assert not torch.equal(a, c)
+    assert float(a.min()) >= 0.0 and float(a.max()) <= 1.0 and torch.isfinite(a).all()
+    # batch-slice invariance: sample 4 images with given noise; images 1..2 alone with the matching noise rows give the same pixels
+    eng = var.engine()
+    V = var.V
+    g = torch.Generator().manual_seed(5)
+    noise = [torch.empty(4 * pn * pn, V).exponential_(1, generator=g) for pn in var.patch_nums]
+    lab = torch.tensor([5, 6, 7, 8], device='cuda')
+    full = eng.sample(4, lab, None, 1.5, 900, 0.96, noises=noise).clone()
+    sub_noise = [n.view(4, -1, V)[1:3].reshape(-1, V) for n in noise]
+    sub = eng.sample(2, lab[1:3], None, 1.5, 900, 0.96, noises=sub_noise)
+    assert torch.equal(full[1:3], sub), 'an image must not depend on its batch neighbours'
+    with pytest.raises(ValueError):
+        eng.sample(2, torch.tensor([5, 1001], device='cuda'), None, 1.5, 0, 0.0)
+    with pytest.raises(NotImplementedError):
+        var.autoregressive_infer_cfg(2, 1, g_seed=0, more_smooth=True)
+
+
+def test_incremental_fhat_equals_embed_to_fhat_and_decoder_api():
+    """SURVEY.md §4 identity (ii): the AR loop's accumulated f_hat == VectorQuantizer2.embed_to_fhat on its tokens (PyTorch,
+    tolerance: different rounding order), and VQVAE.fhat_to_img (HIP decoder via the public API) reproduces the loop's image."""
+    z, meta = util.load_case('t_pn12345')
+    vae, var = build_models(meta)
+    img, tr = hip_run(meta, z)
+    idx = np.concatenate(tr['idx'], axis=1)
+    ms, cur = [], 0
+    for pn in meta['patch_nums']:
+        ms.append(torch.from_numpy(idx[:, cur:cur + pn * pn]).cuda()); cur += pn * pn
+    with torch.inference_mode():
+        hs = [vae.quantize.embedding(i).transpose(1, 2).reshape(len(meta['labels']), vae.Cvae, pn, pn) for i, pn in zip(ms, meta['patch_nums'])]
+        f_ref = vae.quantize.embed_to_fhat(hs, all_to_max_scale=True, last_one=True)
+        ok, m = util.diff_report('f_hat incremental vs embed_to_fhat', tr['f_hat'][-1], f_ref.cpu().numpy(), atol=2e-5, rtol=1e-5)
+        print(m); assert ok, m
+        im2 = vae.fhat_to_img(torch.from_numpy(tr['f_hat'][-1]).cuda()).add_(1).mul_(0.5)
+    ok, m = util.diff_report('fhat_to_img API vs loop image', im2.cpu().numpy(), img, atol=1e-6)
+    print(m); assert ok, m
+
+
+def test_d16_batch64_properties():
+    """BASELINE.json configs[1] at full size (d16, 10 scales, B=64): determinism and agreement of the first two images with the
+    B=2 reference fixture when fed the same noise rows (batch-slice invariance at the headline shape)."""
+    z, meta = util.load_case('d16_full')
+    vae, var = build_models(meta)
+    eng = var.engine()
+    V, B = var.V, 64
+    g = torch.Generator().manual_seed(99)
+    labels = torch.cat([torch.tensor(meta['labels']), (torch.arange(B - 2) * 7) % 1000]).cuda()
+    ref_noise = util.regen_noise(meta, z)
+    noise = []
+    for si, pn in enumerate(meta['patch_nums']):
+        n = torch.empty(B * pn * pn, V).exponential_(1, generator=g).view(B, pn * pn, V)
+        n[:2] = torch.from_numpy(ref_noise[si]).view(2, pn * pn, V)
+        noise.append(n.view(-1, V))
+    img = eng.sample(B, labels, None, meta['cfg'], meta['top_k'], meta['top_p'], noises=noise, trace=True)
+    idx = torch.cat(eng.last_trace['idx'], dim=1).cpu().numpy()
+    ok, m = util.diff_report('B=64: tokens of images 0,1 vs reference fixture', idx[:2].astype(np.int32), z['idx']); print(m); assert ok, m
+    ok, m = util.diff_report('B=64: images 0,1 vs reference fixture', img[:2].cpu().numpy(), z['img'], atol=1e-3); print(m); assert ok, m
+    assert torch.isfinite(img).all() and float(img.min()) >= 0 and float(img.max()) <= 1
+    assert len({tuple(r) for r in idx[:, :30].tolist()}) > 32, 'different labels/noise must give different token maps'

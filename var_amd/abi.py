@@ -1,7 +1,7 @@
 """ctypes signature table of the C ABI declared in include/var_hip.h.
 
 One table, two consumers: var_amd/hip.py binds `varhip_<name>(..., stream)` in libvar_hip.so (the product),
-oracle/var_oracle.py binds `varref_<name>(...)` in libvar_oracle.so (the CPU checker).  Keeping the argument
+the CPU checker under oracle/ binds `varref_<name>(...)` in its own shared library.  Keeping the argument
 lists in one place is what lets the parity tests drive both libraries with identical arguments.
 """
 import ctypes as C

@@ -188,11 +188,11 @@ __global__ void __launch_bounds__(256) k_mfma_gemm(GemmP p) {
                     if (p.gamma) v = v * p.gamma[(int64_t)(m / p.rows_per_group) * p.ldg + n];
                     v = p.resid[(int64_t)m * p.ldr + n] + v;
                 }
-                if (CONV && p.out_mode == 1) {
+                if (CONV && p.out_mode != 0) {
                     const int hw = p.H * p.Wd;
                     const int b = m / hw, rem2 = m - b * hw;
                     v = vm_min(vm_max(v, -1.0f), 1.0f);
-                    Ob[((int64_t)b * p.N + n) * hw + rem2] = (v + 1.0f) * 0.5f;
+                    Ob[((int64_t)b * p.N + n) * hw + rem2] = p.out_mode == 1 ? (v + 1.0f) * 0.5f : v;
                 } else {
                     Ob[(int64_t)m * p.ldo + n] = v;
                 }
@@ -241,7 +241,7 @@ extern "C" int varhip_conv3x3_nhwc_f32(const float* in, const float* w, const fl
                                        int B, int H, int W, int Cin, int Cout, int up2, int out_mode, varhip_stream_t stream) {
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (Cin & 15) || !bias) return VARHIP_EINVAL;
     if (up2 && ((H & 1) || (W & 1))) return VARHIP_EINVAL;
-    if (out_mode < 0 || out_mode > 1 || (out_mode == 1 && resid)) return VARHIP_EINVAL;
+    if (out_mode < 0 || out_mode > 2 || (out_mode != 0 && resid)) return VARHIP_EINVAL;
     if ((int64_t)B * H * W >= (1ll << 31)) return VARHIP_EINVAL;
     GemmP p{};
     p.A = in; p.W = w; p.bias = bias; p.out = out; p.resid = resid; p.gamma = nullptr;

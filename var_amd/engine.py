@@ -1,0 +1,343 @@
+"""Host side of the MI355X sampling path: drives the HIP kernels of libvar_hip.so for one (VAR, VQVAE) pair.
+
+This is what `VAR.autoregressive_infer_cfg` (reference models/var.py:126-190) and `VQVAE.fhat_to_img`
+(models/vqvae.py:62-63) run on a GPU.  PyTorch supplies device memory, the RNG stream and the current HIP stream;
+every floating-point operation of the path happens in a kernel reached through `hip.call` (include/var_hip.h).
+There is no CPU / eager fallback here: without the library `hip.lib()` raises.
+
+Differences from the reference's schedule (results unchanged):
+  * the per-block AdaLN projection `ada_lin(cond)` is computed once per call instead of once per scale
+    (it only depends on the class embedding: basic_var.py:156, var.py:165-169);
+  * the KV cache is pre-allocated [2B, H, L, 64] per block and appended in place (no torch.cat, basic_var.py:107-109);
+  * activations of the decoder are channels-last; f_hat is kept [B, P, P, Cvae] and only transposed at the API edge.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import hip
+from .abi import EPI_GELU, EPI_NONE, EPI_RESID
+
+
+def bicubic_taps(pn: int, P: int):
+    """4-tap index/weight table of F.interpolate(mode='bicubic', align_corners=False) for pn -> P (reference quant.py:190).
+    Follows ATen's upsample_bicubic2d in fp32: src = (pn/P)*(dst+0.5)-0.5, taps floor(src)-1..+2 clamped, Keys kernel A=-0.75."""
+    f = np.float32
+    A = f(-0.75)
+    scale = f(pn) / f(P)
+    src = scale * (np.arange(P, dtype=np.float32) + f(0.5)) - f(0.5)
+    i0 = np.floor(src)
+    t = (src - i0).astype(np.float32)
+
+    def near(x):
+        return ((A + f(2)) * x - (A + f(3))) * x * x + f(1)
+
+    def far(x):
+        return ((A * x - f(5) * A) * x + f(8) * A) * x - f(4) * A
+    w = np.stack([far(t + f(1)), near(t), near(f(1) - t), far((f(1) - t) + f(1))], axis=1).astype(np.float32)
+    idx = np.clip(i0.astype(np.int64)[:, None] - 1 + np.arange(4)[None, :], 0, pn - 1).astype(np.int32)
+    return idx, w
+
+
+def phi_index(si: int, S: int, K: int) -> int:
+    """which shared Phi conv serves scale si (reference quant.py:218-226)"""
+    ticks = np.linspace(1 / 3 / K, 1 - 1 / 3 / K, K) if K == 4 else np.linspace(1 / 2 / K, 1 - 1 / 2 / K, K)
+    return int(np.argmin(np.abs(ticks - si / (S - 1)))) if S > 1 else 0
+
+
+def _chk(t: torch.Tensor, name: str) -> torch.Tensor:
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise hip.VarHipError(f'{name}: the MI355X sampling path needs fp32 CUDA parameters, got {t.dtype} on {t.device}')
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class DecoderEngine:
+    """VQVAE.fhat_to_img on HIP kernels (reference vqvae.py:62-63, basic_vae.py:163-226)."""
+
+    def __init__(self, vae):
+        self.vae = vae
+        self._sig = None
+        self.w: Dict[str, torch.Tensor] = {}
+
+    def _signature(self):
+        return tuple((p.data_ptr(), p._version) for p in self.vae.parameters())
+
+    def refresh(self):
+        sig = self._signature()
+        if sig == self._sig:
+            return
+        sd = {k: v for k, v in self.vae.state_dict().items()}
+        w = {}
+        for k, v in sd.items():
+            if k.startswith('encoder.') or k.startswith('quant_conv.') or not torch.is_floating_point(v):
+                continue
+            v = _chk(v.detach(), k)
+            if v.dim() == 4 and v.shape[-1] == 3:
+                w[k] = v.permute(0, 2, 3, 1).contiguous()          # [Cout][Cin][3][3] -> [Cout][3][3][Cin]
+            elif v.dim() == 4:
+                w[k] = v.reshape(v.shape[0], v.shape[1])            # 1x1 conv == linear
+            else:
+                w[k] = v
+        self.w = w
+        self.nlev = 1 + max(int(k.split('.')[2]) for k in w if k.startswith('decoder.up.'))
+        self._sig = sig
+
+    # -- building blocks ---------------------------------------------------------------------------------------------
+    def conv3(self, x, key, B, Hh, Ww, up2=0, resid=None, out_mode=0):
+        wt = self.w[key + '.weight']
+        Cout, Cin = wt.shape[0], wt.shape[3]
+        out = torch.empty((B, Cout, Hh, Ww) if out_mode else (B, Hh, Ww, Cout), dtype=torch.float32, device=x.device)
+        hip.call('conv3x3_nhwc_f32', x, wt, self.w[key + '.bias'], resid, out, B, Hh, Ww, Cin, Cout, up2, out_mode)
+        return out
+
+    def gn(self, x, key, B, HW, silu):
+        Cc = x.shape[-1]
+        stats = torch.empty((B, 32, 2), dtype=torch.float32, device=x.device)
+        scratch = torch.empty(hip.gn_scratch_elems(B, HW, Cc, 32), dtype=torch.float64, device=x.device)
+        hip.call('gn_stats_f32', x, stats, scratch, B, HW, Cc, 32, 1e-6)
+        out = torch.empty_like(x)
+        hip.call('gn_apply_f32', x, stats, self.w[key + '.weight'], self.w[key + '.bias'], out, B, HW, Cc, 32, int(silu))
+        return out
+
+    def lin(self, x2d, key, resid=None):
+        wt = self.w[key + '.weight']
+        N, K = wt.shape
+        M = x2d.shape[0]
+        out = torch.empty((M, N), dtype=torch.float32, device=x2d.device)
+        hip.call('gemm_nt_f32', x2d, K, wt, K, self.w[key + '.bias'], out, N, M, N, K, EPI_RESID if resid is not None else EPI_NONE,
+                 resid, N, None, 0, 1, 0, 1, 0, 0, 0)
+        return out
+
+    def resblock(self, x, pre, B, Hh, Ww):
+        HW = Hh * Ww
+        h = self.conv3(self.gn(x, pre + '.norm1', B, HW, True), pre + '.conv1', B, Hh, Ww)
+        sc = self.lin(x.view(B * HW, -1), pre + '.nin_shortcut').view(B, Hh, Ww, -1) if (pre + '.nin_shortcut.weight') in self.w else x
+        return self.conv3(self.gn(h, pre + '.norm2', B, HW, True), pre + '.conv2', B, Hh, Ww, resid=sc)
+
+    def attnblock(self, x, pre, B, Hh, Ww):
+        HW, Cc = Hh * Ww, x.shape[-1]
+        dev = x.device
+        xn = self.gn(x, pre + '.norm', B, HW, False).view(B * HW, Cc)
+        wqkv, bqkv = self.w[pre + '.qkv.weight'], self.w[pre + '.qkv.bias']
+        qk = torch.empty((B * HW, 2 * Cc), dtype=torch.float32, device=dev)
+        hip.call('gemm_nt_f32', xn, Cc, wqkv, Cc, bqkv, qk, 2 * Cc, B * HW, 2 * Cc, Cc, EPI_NONE, None, 0, None, 0, 1, 0, 1, 0, 0, 0)
+        vt = torch.empty((B, Cc, HW), dtype=torch.float32, device=dev)                   # V^T[b][c][j], bias per row (c)
+        hip.call('gemm_nt_f32', wqkv[2 * Cc:], Cc, xn, Cc, bqkv[2 * Cc:], vt, HW, Cc, HW, Cc, EPI_NONE, None, 0, None, 0, 1, 1,
+                 B, 0, HW * Cc, Cc * HW)
+        s = torch.empty((B, HW, HW), dtype=torch.float32, device=dev)
+        hip.call('gemm_nt_f32', qk, 2 * Cc, qk[:, Cc:], 2 * Cc, None, s, HW, HW, HW, Cc, EPI_NONE, None, 0, None, 0, 1, 0,
+                 B, HW * 2 * Cc, HW * 2 * Cc, HW * HW)
+        p = torch.empty_like(s)
+        hip.call('softmax_rows_f32', s, p, B * HW, HW, float(np.float32(int(Cc) ** (-0.5))))
+        o = torch.empty((B * HW, Cc), dtype=torch.float32, device=dev)
+        hip.call('gemm_nt_f32', p, HW, vt, HW, None, o, Cc, HW, Cc, HW, EPI_NONE, None, 0, None, 0, 1, 0, B, HW * HW, Cc * HW, HW * Cc)
+        return self.lin(o, pre + '.proj_out', resid=x.view(B * HW, Cc)).view(B, Hh, Ww, Cc)
+
+    def decode_nhwc(self, f_hat: torch.Tensor, denorm: bool = True) -> torch.Tensor:
+        """[B,P,P,Cvae] channels-last -> [B,3,16P,16P]; denorm=True: in [0,1] (clamp and (x+1)/2 fused into the last conv, what
+        autoregressive_infer_cfg returns); denorm=False: clamped to [-1,1] (VQVAE.fhat_to_img's contract)"""
+        self.refresh()
+        B, P = f_hat.shape[0], f_hat.shape[1]
+        Hh = Ww = P
+        h = self.conv3(f_hat, 'post_quant_conv', B, Hh, Ww)
+        h = self.conv3(h, 'decoder.conv_in', B, Hh, Ww)
+        h = self.resblock(h, 'decoder.mid.block_1', B, Hh, Ww)
+        h = self.attnblock(h, 'decoder.mid.attn_1', B, Hh, Ww)
+        h = self.resblock(h, 'decoder.mid.block_2', B, Hh, Ww)
+        for lev in reversed(range(self.nlev)):
+            for ib in range(3):
+                h = self.resblock(h, f'decoder.up.{lev}.block.{ib}', B, Hh, Ww)
+                if f'decoder.up.{lev}.attn.{ib}.norm.weight' in self.w:
+                    h = self.attnblock(h, f'decoder.up.{lev}.attn.{ib}', B, Hh, Ww)
+            if lev != 0:
+                Hh, Ww = 2 * Hh, 2 * Ww
+                h = self.conv3(h, f'decoder.up.{lev}.upsample.conv', B, Hh, Ww, up2=1)
+        h = self.gn(h, 'decoder.norm_out', B, Hh * Ww, True)
+        return self.conv3(h, 'decoder.conv_out', B, Hh, Ww, out_mode=1 if denorm else 2)
+
+
+class SamplingEngine:
+    """The AR loop of VAR.autoregressive_infer_cfg on HIP kernels.  One engine per VAR module; not re-entrant."""
+
+    def __init__(self, var):
+        self.var = var
+        self._sig = None
+        self._ws: Dict[int, dict] = {}
+        self.dec = DecoderEngine(var.vae_proxy[0])
+        self.last_trace: Optional[dict] = None
+
+    # -- weights -----------------------------------------------------------------------------------------------------
+    def refresh(self):
+        var = self.var
+        quant = var.vae_quant_proxy[0]
+        sig = tuple((p.data_ptr(), p._version) for p in list(var.parameters()) + list(quant.parameters()))
+        if sig == self._sig:
+            return
+        dev = var.pos_start.device
+        w = {}
+        g = lambda t, n: _chk(t.detach(), n)
+        C = var.C
+        w['class_emb'] = g(var.class_emb.weight, 'class_emb')
+        w['pos_start'] = g(var.pos_start, 'pos_start').view(var.first_l, C)
+        w['pos_1LC'] = g(var.pos_1LC, 'pos_1LC').view(var.L, C)
+        w['lvl_embed'] = g(var.lvl_embed.weight, 'lvl_embed')
+        w['lvl_1L'] = var.lvl_1L.view(-1).to(torch.int64).contiguous()
+        w['word_w'], w['word_b'] = g(var.word_embed.weight, 'word_embed.weight'), g(var.word_embed.bias, 'word_embed.bias')
+        w['head_w'], w['head_b'] = g(var.head.weight, 'head.weight'), g(var.head.bias, 'head.bias')
+        w['hn_w'], w['hn_b'] = g(var.head_nm.ada_lin[1].weight, 'head_nm'), g(var.head_nm.ada_lin[1].bias, 'head_nm')
+        if var.shared_aln:
+            w['sal_w'], w['sal_b'] = g(var.shared_ada_lin[1].weight, 'shared_ada_lin'), g(var.shared_ada_lin[1].bias, 'shared_ada_lin')
+        blocks = []
+        for b in var.blocks:
+            a = b.attn
+            d = dict(
+                qkv_w=g(a.mat_qkv.weight, 'mat_qkv'), qkv_b=torch.cat((a.q_bias.detach(), a.zero_k_bias, a.v_bias.detach())).float().contiguous(),
+                proj_w=g(a.proj.weight, 'proj'), proj_b=g(a.proj.bias, 'proj'),
+                fc1_w=g(b.ffn.fc1.weight, 'fc1'), fc1_b=g(b.ffn.fc1.bias, 'fc1'), fc2_w=g(b.ffn.fc2.weight, 'fc2'), fc2_b=g(b.ffn.fc2.bias, 'fc2'),
+                smul=g(a.scale_mul_1H11, 'scale_mul').view(-1) if a.attn_l2_norm else None, l2=bool(a.attn_l2_norm), plain_scale=float(a.scale))
+            if var.shared_aln:
+                d['gss'] = g(b.ada_gss, 'ada_gss').view(-1)
+            else:
+                d['ada_w'], d['ada_b'] = g(b.ada_lin[1].weight, 'ada_lin'), g(b.ada_lin[1].bias, 'ada_lin')
+            blocks.append(d)
+        w['blocks'] = blocks
+        w['codebook'] = g(quant.embedding.weight, 'codebook')
+        phis = list(quant.quant_resi.phis())
+        w['phi'] = [(g(p.weight, 'phi').permute(0, 2, 3, 1).contiguous(), g(p.bias, 'phi'), float(p.resi_ratio)) for p in phis]
+        w['taps'] = {}
+        P = var.patch_nums[-1]
+        for pn in var.patch_nums:
+            if pn != P:
+                ti, tw = bicubic_taps(pn, P)
+                w['taps'][pn] = (torch.from_numpy(ti).to(dev), torch.from_numpy(tw).to(dev))
+        self.w = w
+        self._sig = sig
+
+    # -- workspaces --------------------------------------------------------------------------------------------------
+    def workspace(self, B: int):
+        ws = self._ws.get(B)
+        dev = self.var.pos_start.device
+        if ws is not None and ws['dev'] == dev:
+            return ws
+        var = self.var
+        C, L, H, V, Cv, P = var.C, var.L, var.num_heads, var.V, var.Cvae, var.patch_nums[-1]
+        lmax = max(p * p for p in var.patch_nums)
+        M = 2 * B * lmax
+        hid = var.blocks[0].ffn.fc1.weight.shape[0]
+        e = lambda *s, dt=torch.float32: torch.empty(*s, dtype=dt, device=dev)
+        ws = dict(dev=dev, x=e(M, C), x2=e(M, C), xn=e(M, C), qkv=e(M, 3 * C), q=e(M, C), att=e(M, C), hid=e(M, hid), logits=e(M, V),
+                  idx=e(B * lmax, dt=torch.int64), lvl_pos=e(L, C), cond=e(2 * B, C), cond_silu=e(2 * B, C), hn=e(2 * B, 2 * C),
+                  ada=e(var.depth, 2 * B, 6 * C), shared=e(2 * B, 6 * C) if var.shared_aln else None,
+                  kc=[torch.zeros(2 * B, H, L, 64, dtype=torch.float32, device=dev) for _ in range(var.depth)],
+                  vc=[torch.zeros(2 * B, H, L, 64, dtype=torch.float32, device=dev) for _ in range(var.depth)],
+                  f_hat=e(B, P, P, Cv), up=e(B, P, P, Cv), pooled=e(B * lmax, Cv))
+        self._ws = {B: ws}          # one batch size resident at a time
+        return ws
+
+    def gemm(self, A, W, bias, out, M, epi=EPI_NONE, resid=None, gamma=None, ldg=0, rpg=1):
+        N, K = W.shape
+        hip.call('gemm_nt_f32', A, K, W, K, bias, out, N, M, N, K, epi, resid, N, gamma, ldg, rpg, 0, 1, 0, 0, 0)
+
+    # -- the loop ----------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def sample(self, B: int, label_B: torch.Tensor, rng: Optional[torch.Generator], cfg: float, top_k: int, top_p: float,
+               noises=None, force_idx: Optional[torch.Tensor] = None, trace: bool = False,
+               decode: bool = True) -> torch.Tensor:
+        """label_B: int64 [B] on the device.  noises: optional per-scale Exp(1) tensors [B*l, V] — a list, or a callable
+        (si, l) -> tensor (tests inject the CPU generator's stream; var_amd.multi hands each rank its rows); by default they are drawn with `exponential_(generator=rng)` exactly as torch.multinomial
+        (helpers.py:19) would.  force_idx/trace are test hooks (teacher forcing; keep per-scale logits/tokens/f_hat)."""
+        var = self.var
+        self.refresh()
+        w, ws = self.w, self.workspace(B)
+        dev = ws['dev']
+        C, H, V, Cv, S = var.C, var.num_heads, var.V, var.Cvae, len(var.patch_nums)
+        P, B2 = var.patch_nums[-1], 2 * B
+        if label_B.dtype != torch.int64 or label_B.numel() != B:
+            raise ValueError('label_B must be an int64 tensor of B labels')
+        if int(label_B.min()) < 0 or int(label_B.max()) > var.num_classes:
+            raise ValueError(f'labels must lie in [0, {var.num_classes}]')
+        label_B = label_B.to(dev).contiguous()
+        tr = dict(logits=[], idx=[], f_hat=[], pooled=[]) if trace else None
+
+        # prologue (var.py:151-157)
+        hip.call('lvl_pos_f32', w['lvl_embed'], w['lvl_1L'], w['pos_1LC'], ws['lvl_pos'], var.L, C)
+        hip.call('first_map_f32', w['class_emb'], label_B, var.num_classes, w['pos_start'], ws['lvl_pos'], ws['cond'], ws['x'], B, C, var.first_l)
+        hip.call('silu_f32', ws['cond'], ws['cond_silu'], B2 * C)
+        ws['f_hat'].zero_()
+        # AdaLN parameters of every block, once per call
+        if var.shared_aln:
+            self.gemm(ws['cond_silu'], w['sal_w'], w['sal_b'], ws['shared'], B2)
+        for bi, blk in enumerate(w['blocks']):
+            if var.shared_aln:
+                hip.call('add_bcast_f32', blk['gss'], ws['shared'], ws['ada'][bi], B2, 6 * C)
+            else:
+                self.gemm(ws['cond_silu'], blk['ada_w'], blk['ada_b'], ws['ada'][bi], B2)
+        self.gemm(ws['cond_silu'], w['hn_w'], w['hn_b'], ws['hn'], B2)
+
+        x, x2 = ws['x'], ws['x2']
+        cur = 0
+        for si, pn in enumerate(var.patch_nums):                          # var.py:160
+            l = pn * pn
+            M = B2 * l
+            for bi, blk in enumerate(w['blocks']):                        # AdaLNSelfAttn.forward, basic_var.py:152-159
+                ada = ws['ada'][bi]
+                g1, g2, s1, s2, h1, h2 = (ada[:, i * C:] for i in range(6))       # interior pointers, row stride 6C
+                hip.call('ln_modulate_f32', x, s1, 6 * C, h1, 6 * C, ws['xn'], M, C, l, var.norm_eps)
+                self.gemm(ws['xn'], blk['qkv_w'], blk['qkv_b'], ws['qkv'], M)
+                hip.call('qkv_prep_f32', ws['qkv'], blk['smul'], blk['plain_scale'], int(blk['l2']), ws['q'], ws['kc'][bi], ws['vc'][bi],
+                         B2, l, H, cur, var.L)
+                hip.call('attn_cached_f32', ws['q'], ws['kc'][bi], ws['vc'][bi], ws['att'], B2, l, H, cur + l, var.L)
+                self.gemm(ws['att'], blk['proj_w'], blk['proj_b'], x2, M, EPI_RESID, resid=x, gamma=g1, ldg=6 * C, rpg=l)
+                hip.call('ln_modulate_f32', x2, s2, 6 * C, h2, 6 * C, ws['xn'], M, C, l, var.norm_eps)
+                self.gemm(ws['xn'], blk['fc1_w'], blk['fc1_b'], ws['hid'], M, EPI_GELU)
+                self.gemm(ws['hid'], blk['fc2_w'], blk['fc2_b'], x, M, EPI_RESID, resid=x2, gamma=g2, ldg=6 * C, rpg=l)
+            cur += l
+            # get_logits (var.py:118-124): AdaLNBeforeHead + head
+            hn = ws['hn']
+            hip.call('ln_modulate_f32', x, hn, 2 * C, hn[:, C:], 2 * C, ws['xn'], M, C, l, var.norm_eps)
+            self.gemm(ws['xn'], w['head_w'], w['head_b'], ws['logits'], M)
+            if trace: tr['logits'].append(ws['logits'][:M].view(B2, l, V).clone())
+            # CFG + top-k/top-p + multinomial (var.py:172-175)
+            if noises is not None:
+                noise = (noises(si, l) if callable(noises) else noises[si]).to(dev, torch.float32).contiguous()
+            else:
+                noise = torch.empty(B * l, V, dtype=torch.float32, device=dev).exponential_(1, generator=rng)
+            t = cfg * (si / var.num_stages_minus_1) if var.num_stages_minus_1 > 0 else 0.0
+            idx = ws['idx'][:B * l]
+            hip.call('cfg_sample_f32', ws['logits'], noise, idx, None, B, l, V, float(t), int(top_k), float(top_p))
+            if trace: tr['idx'].append(idx.view(B, l).clone())
+            if force_idx is not None:
+                idx = force_idx[:, cur - l:cur].to(dev, torch.int64).contiguous().view(-1)
+            # quantizer step (var.py:177-183)
+            ti, tw = w['taps'].get(pn, (None, None))
+            pw, pb, ratio = w['phi'][phi_index(si, S, len(w['phi']))]
+            hip.call('quant_accum_f32', idx, w['codebook'], ti, tw, pw, pb, ratio, ws['up'], ws['f_hat'], B, pn, P, Cv)
+            if trace: tr['f_hat'].append(ws['f_hat'].permute(0, 3, 1, 2).clone())
+            if si != S - 1:
+                pq = var.patch_nums[si + 1]
+                hip.call('next_map_f32', ws['f_hat'], w['word_w'], w['word_b'], ws['lvl_pos'][cur:], x, ws['pooled'], B, P, pq, C, Cv)
+                if trace: tr['pooled'].append(ws['pooled'][:B * pq * pq].view(B, pq, pq, Cv).permute(0, 3, 1, 2).clone())
+        self.last_trace = tr
+        if not decode:
+            return ws['f_hat'].permute(0, 3, 1, 2).contiguous()
+        return self.dec.decode_nhwc(ws['f_hat'])                          # var.py:190
+
+    # -- model arithmetic (for bench.py's roofline) -------------------------------------------------------------------
+    def flops_per_image(self) -> float:
+        """Algorithmic FLOPs of one image (2 per MAC, both CFG branches), SURVEY.md §8(d) formula; ada_lin hoisted."""
+        var = self.var
+        C, depth, V = var.C, var.depth, var.V
+        L = var.L
+        T = 2 * L
+        sig = 0; cur = 0
+        for pn in var.patch_nums:
+            cur += pn * pn; sig += pn * pn * cur
+        lin = 2 * 12 * C * C * depth * T
+        att = 2 * 2 * sig * C * depth * 2
+        head = 2 * C * V * T
+        ada = 2 * 2 * depth * 6 * C * C
+        return float(lin + att + head + ada)
