@@ -125,17 +125,19 @@ def cpu_baseline(depth, pns):
     var_sd['lvl_1L'] = np.concatenate([np.full((p * p,), i, dtype=np.int64) for i, p in enumerate(pns)]).reshape(1, -1)
     vae_sd = make_state_dict(shapes.vae_shapes(ch=160, patch_nums=pns, include_encoder=False), depth=depth, seed=0, prefix='vae.')
     orc = OracleVAR(var_sd, vae_sd, pns, depth)
+    import ctypes
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    so = ctypes.CDLL(os.path.join(ROOT, 'oracle', 'libvar_oracle.so'))
+    threads = int(so.varref_set_threads(int(os.environ.get('OMP_NUM_THREADS', min(avail, 16)))))   # a 1-GPU box's CPU share is 16 cores
     g = torch.Generator().manual_seed(0)
     noise = [torch.empty(pn * pn, 4096).exponential_(1, generator=g).numpy() for pn in pns]
     t0 = time.perf_counter()
     r = orc.run([7], noise, 1.5, 900, 0.96)
     dt = time.perf_counter() - t0
     assert np.isfinite(r['img']).all()
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count()
-    threads = int(os.environ.get('OMP_NUM_THREADS', cores))
     return {'value': round(1.0 / dt, 4), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
             'sample': f'1 image (label 7), all 10 scales + VQVAE decode, oracle/var_oracle.c via OpenMP: {dt:.1f} s'}
 

@@ -42,7 +42,7 @@ const char* varhip_version(void);
  *                           gamma == NULL means no scaling: resid + (acc + bias)       (basic_vae.py:60,92)
  *   bias may be NULL.  bias_per_row != 0: bias is indexed by m instead of n.
  *   batch >= 1 with element strides sA/sW/sO (sW or sA may be 0 to share an operand); resid/gamma only with batch==1.
- * Constraints: K % 8 == 0, lda/ldw % 4 == 0, pointers 16-byte aligned. */
+ * Fast path: K % 8 == 0, lda/ldw/sA/sW % 4 == 0 and 16-byte aligned A/W; anything else takes an element-wise-load variant. */
 #define VARHIP_EPI_NONE 0
 #define VARHIP_EPI_GELU 1
 #define VARHIP_EPI_RESID 2
@@ -153,8 +153,9 @@ int varhip_nearest_code_f32(const float* z, const float* codebook, int64_t* idx_
 /* ---- per-kernel timing (bench.py's roofline leg) -----------------------------------------------------------
  * When enabled, every launch is bracketed by hipEvents on its own stream and its algorithmic FLOPs and bytes are
  * accumulated per kernel family.  varhip_timing_read synchronises the recorded events.
- * families: 0 gemm, 1 conv3x3, 2 attn, 3 sampler, 4 ln, 5 qkv_prep, 6 gn, 7 other.  Returns the number of families. */
-#define VARHIP_NFAM 8
+ * families: 0 gemm (128x128-tile kernel), 1 conv3x3, 2 attn, 3 sampler, 4 ln, 5 qkv_prep, 6 gn, 7 other, 8 gemm_small (64x64-tile
+ * and element-wise-load variants).  Returns the number of families. */
+#define VARHIP_NFAM 9
 int varhip_timing_enable(int on);
 int varhip_timing_reset(void);
 int varhip_timing_read(double* ms, double* flops, double* bytes, int64_t* launches);

@@ -56,6 +56,14 @@ static float canon_sum256(const float* x, int n) {
 
 const char* varref_version(void) { return "var_oracle 0.1 (cpu restatement)"; }
 
+/* OpenMP team size used by every function below (bench.py reports it as cpu_baseline.cores) */
+#ifdef _OPENMP
+#include <omp.h>
+int varref_set_threads(int n) { if (n > 0) omp_set_num_threads(n); return omp_get_max_threads(); }
+#else
+int varref_set_threads(int n) { (void)n; return 1; }
+#endif
+
 /* ================================================================================================================
  * GEMM  out = epi(A . W^T + bias)        reference: F.linear at basic_var.py:93,119,52,147,170; var.py:124;
  * 1x1 convs and bmm's of basic_vae.py:53,69,71,83,89.   Wt is W transposed to [K][N] (so the n loop vectorises;

@@ -66,7 +66,7 @@ def test_library_loads_and_reports_version():
     assert torch.cuda.is_available()
 
 
-@pytest.mark.parametrize('M,N,K', [(128, 128, 128), (4, 384, 128), (36, 512, 128), (300, 320, 640), (1152, 1024, 1024), (2048, 3072, 1024), (64, 4096, 256), (1, 128, 32), (130, 40, 8)])
+@pytest.mark.parametrize('M,N,K', [(128, 128, 128), (4, 384, 128), (36, 512, 128), (300, 320, 640), (1152, 1024, 1024), (2048, 3072, 1024), (64, 4096, 256), (1, 128, 32), (130, 40, 8), (9, 128, 9), (25, 33, 25), (70, 70, 13)])
 @pytest.mark.parametrize('epi', [0, 1, 2])
 def test_gemm_exact(M, N, K, epi):
     rng = np.random.default_rng(M * 7 + N * 3 + K + epi)
@@ -93,7 +93,7 @@ def test_gemm_rejects_bad_shapes():
     from var_amd.hip import VarHipError
     a = torch.zeros(64, 36, device='cuda')
     with pytest.raises(VarHipError):
-        hip.call('gemm_nt_f32', a, 36, a, 36, None, a, 64, 64, 64, 36, 0, None, 0, None, 0, 1, 0, 1, 0, 0, 0)     # K % 8 != 0
+        hip.call('gemm_nt_f32', a, 36, a, 36, None, a, 64, 64, 64, 0, 0, None, 0, None, 0, 1, 0, 1, 0, 0, 0)      # K == 0
     with pytest.raises(VarHipError):
         hip.call('gemm_nt_f32', a, 36, a, 36, None, a, 64, 64, 64, 32, 2, None, 0, None, 0, 1, 0, 1, 0, 0, 0)     # RESID without resid
 

@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Micro-benchmarks of the hot kernels at the shapes the d16 / B=64 sampling call launches (run on the GPU box).
+
+  python tools/bench_kernels.py gemm|conv|attn|all [--iters N]
+Times each shape with torch CUDA events on the launch stream, interleaving shapes over rounds (cdna guide rule 24), and
+prints TFLOP/s against the fp32 MFMA peak.  Used to A/B kernel variants; numbers quoted in DESIGN.md come from bench.py."""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from var_amd import hip      # noqa: E402
+
+PEAK = 157.3
+
+
+def timeit(fn, iters):
+    fn(); torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def gemm_shapes():
+    B2 = 128
+    out = []
+    for l in (256, 169, 100, 64, 36, 16, 4, 1):
+        M = B2 * l
+        out += [(f'qkv  l={l}', M, 3072, 1024, 0), (f'proj l={l}', M, 1024, 1024, 2), (f'fc1  l={l}', M, 4096, 1024, 1), (f'fc2  l={l}', M, 1024, 4096, 2)]
+    out.append(('square 4096', 4096, 4096, 4096, 0))
+    out.append(('square 8192', 8192, 8192, 8192, 0))
+    return out
+
+
+def run_gemm(iters, rounds=3):
+    dev = 'cuda'
+    res = {}
+    bufs = {}
+    for name, M, N, K, epi in gemm_shapes():
+        A = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev) * 0.03; b = torch.randn(N, device=dev)
+        out = torch.empty(M, N, device=dev); resid = torch.randn(M, N, device=dev); gamma = torch.randn(128, N, device=dev)
+        bufs[name] = (A, W, b, out, resid, gamma)
+    for r in range(rounds):
+        for name, M, N, K, epi in gemm_shapes():
+            A, W, b, out, resid, gamma = bufs[name]
+            rpg = max(M // 128, 1)
+            fn = lambda: hip.call('gemm_nt_f32', A, K, W, K, b, out, N, M, N, K, epi, resid if epi == 2 else None, N, gamma if epi == 2 else None, N, rpg, 0, 1, 0, 0, 0)
+            ms = timeit(fn, iters if M * N * K > 1e10 else iters * 4)
+            res.setdefault(name, []).append(ms)
+    for name, M, N, K, epi in gemm_shapes():
+        ms = min(res[name]); tf = 2.0 * M * N * K / ms / 1e9
+        print(f'gemm {name:14s} M={M:6d} N={N:5d} K={K:5d} epi={epi}: {ms*1e3:9.1f} us  {tf:7.1f} TF  {tf/PEAK*100:5.1f}%', flush=True)
+
+
+def run_conv(iters):
+    dev = 'cuda'
+    for (B, H, W, Cin, Cout, up2, res) in [(64, 256, 256, 160, 160, 0, 1), (64, 256, 256, 160, 160, 1, 0), (64, 128, 128, 320, 160, 0, 0), (64, 128, 128, 160, 160, 0, 1),
+                                           (64, 128, 128, 320, 320, 1, 0), (64, 64, 64, 320, 320, 0, 1), (64, 32, 32, 640, 320, 0, 0), (64, 16, 16, 640, 640, 0, 1),
+                                           (64, 256, 256, 160, 3, 0, 0)]:
+        Hi, Wi = (H // 2, W // 2) if up2 else (H, W)
+        x = torch.randn(B, Hi, Wi, Cin, device=dev); w = torch.randn(Cout, 3, 3, Cin, device=dev) * 0.02; b = torch.randn(Cout, device=dev)
+        r = torch.randn(B, H, W, Cout, device=dev) if res else None
+        out = torch.empty(B, H, W, Cout, device=dev)
+        fn = lambda: hip.call('conv3x3_nhwc_f32', x, w, b, r, out, B, H, W, Cin, Cout, up2, 0)
+        ms = timeit(fn, max(iters // 4, 2)); tf = 2.0 * B * H * W * Cout * 9 * Cin / ms / 1e9
+        print(f'conv {Cin:3d}->{Cout:3d} {H:3d}x{W:3d} up{up2} res{res}: {ms:8.3f} ms  {tf:7.1f} TF  {tf/PEAK*100:5.1f}%', flush=True)
+        del x, w, out, r
+
+
+def run_attn(iters):
+    dev = 'cuda'
+    B2, H, Lmax = 128, 16, 680
+    kc = torch.randn(B2, H, Lmax, 64, device=dev); vc = torch.randn(B2, H, Lmax, 64, device=dev)
+    cur = 0
+    for pn in (1, 2, 3, 4, 5, 6, 8, 10, 13, 16):
+        l = pn * pn; cur += l
+        q = torch.randn(B2 * l, H * 64, device=dev); out = torch.empty_like(q)
+        fn = lambda: hip.call('attn_cached_f32', q, kc, vc, out, B2, l, H, cur, Lmax)
+        ms = timeit(fn, iters); tf = 4.0 * B2 * H * l * cur * 64 / ms / 1e9
+        print(f'attn l={l:3d} curL={cur:3d}: {ms*1e3:9.1f} us  {tf:6.1f} TF (algorithmic)', flush=True)
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('what', nargs='?', default='all')
+    ap.add_argument('--iters', type=int, default=10)
+    a = ap.parse_args()
+    torch.cuda.set_device(0)
+    print(hip.lib().version())
+    if a.what in ('gemm', 'all'): run_gemm(a.iters)
+    if a.what in ('conv', 'all'): run_conv(a.iters)
+    if a.what in ('attn', 'all'): run_attn(a.iters)

@@ -16,6 +16,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define VH_FAM_QKV 5
 #define VH_FAM_GN 6
 #define VH_FAM_OTHER 7
+#define VH_FAM_GEMM_SMALL 8
 
 // ---- timing table (timing.cpp) ------------------------------------------------------------------------------------
 int vh_timing_on();

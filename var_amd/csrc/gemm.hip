@@ -22,7 +22,7 @@ struct GemmP {
     int tilesM, tilesN;
 };
 
-template <int TM, int TN, int WGM, int WGN, int BK, bool CONV>
+template <int TM, int TN, int WGM, int WGN, int BK, bool CONV, bool VEC>
 __global__ void __launch_bounds__(256) k_mfma_gemm(GemmP p) {
     constexpr int BM = TM * 32 * WGM, BN = TN * 32 * WGN, LDSW = BK + 4, CPR = BK / 8;
     constexpr int NA = (BM * CPR + 255) / 256, NB = (BN * CPR + 255) / 256;
@@ -99,15 +99,25 @@ __global__ void __launch_bounds__(256) k_mfma_gemm(GemmP p) {
             } else {
                 src = a_ptr[i] + k0;
             }
-            if (ok) { ra[i][0] = *(const f32x4*)src; ra[i][1] = *(const f32x4*)(src + 4); }
-            else { ra[i][0] = zero4; ra[i][1] = zero4; }
+            if (VEC) {
+                if (ok) { ra[i][0] = *(const f32x4*)src; ra[i][1] = *(const f32x4*)(src + 4); }
+                else { ra[i][0] = zero4; ra[i][1] = zero4; }
+            } else {            // any K / leading dimension / alignment: element-wise guarded loads (small shapes only)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ra[i][e >> 2][e & 3] = (ok && k0 + a_c[i] * 8 + e < p.K) ? src[e] : 0.f;
+            }
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const bool ok = b_ok[i] && (k0 + b_c[i] * 8 < p.K);
             const float* src = b_ptr[i] + k0;
-            if (ok) { rb[i][0] = *(const f32x4*)src; rb[i][1] = *(const f32x4*)(src + 4); }
-            else { rb[i][0] = zero4; rb[i][1] = zero4; }
+            if (VEC) {
+                if (ok) { rb[i][0] = *(const f32x4*)src; rb[i][1] = *(const f32x4*)(src + 4); }
+                else { rb[i][0] = zero4; rb[i][1] = zero4; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) rb[i][e >> 2][e & 3] = (ok && k0 + b_c[i] * 8 + e < p.K) ? src[e] : 0.f;
+            }
         }
     };
     auto store_tile = [&](int stage) {
@@ -201,12 +211,12 @@ __global__ void __launch_bounds__(256) k_mfma_gemm(GemmP p) {
     }
 }
 
-template <int TM, int TN, int WGM, int WGN, int BK, bool CONV>
+template <int TM, int TN, int WGM, int WGN, int BK, bool CONV, bool VEC = true>
 static int launch_gemm(GemmP& p, int batch, hipStream_t stream) {
     constexpr int BM = TM * 32 * WGM, BN = TN * 32 * WGN;
     constexpr size_t lds = 2 * (size_t)(BM + BN) * (BK + 4) * sizeof(float);
     p.tilesM = (p.M + BM - 1) / BM; p.tilesN = (p.N + BN - 1) / BN;
-    auto kfn = k_mfma_gemm<TM, TN, WGM, WGN, BK, CONV>;
+    auto kfn = k_mfma_gemm<TM, TN, WGM, WGN, BK, CONV, VEC>;
     static bool attr_done = false;
     if (!attr_done) {
         if (lds > 48 * 1024) hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -221,8 +231,8 @@ extern "C" int varhip_gemm_nt_f32(const float* A, int64_t lda, const float* W, i
                                   float* out, int64_t ldo, int M, int N, int K, int epi,
                                   const float* resid, int64_t ldr, const float* gamma, int64_t ldg, int rows_per_group,
                                   int bias_per_row, int batch, int64_t sA, int64_t sW, int64_t sO, varhip_stream_t stream) {
-    if (M < 0 || N <= 0 || K <= 0 || batch < 1 || (K & 7) || (lda & 3) || (ldw & 3)) return VARHIP_EINVAL;
-    if (((uintptr_t)A | (uintptr_t)W) & 15) return VARHIP_EINVAL;
+    if (M < 0 || N <= 0 || K <= 0 || batch < 1) return VARHIP_EINVAL;
+    const bool vec = !((K & 7) || (lda & 3) || (ldw & 3) || (sA & 3) || (sW & 3) || (((uintptr_t)A | (uintptr_t)W) & 15));
     if (batch > 1 && (resid || gamma)) return VARHIP_EINVAL;
     if (epi < 0 || epi > 2 || (epi == VARHIP_EPI_RESID && !resid)) return VARHIP_EINVAL;
     if (M == 0) return 0;
@@ -230,9 +240,10 @@ extern "C" int varhip_gemm_nt_f32(const float* A, int64_t lda, const float* W, i
     p.A = A; p.W = W; p.bias = bias; p.out = out; p.resid = resid; p.gamma = gamma;
     p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.ldr = ldr; p.ldg = ldg; p.sA = sA; p.sW = sW; p.sO = sO;
     p.M = M; p.N = N; p.K = K; p.epi = epi; p.rows_per_group = rows_per_group > 0 ? rows_per_group : 1; p.bias_per_row = bias_per_row;
-    VhScope scope(VH_FAM_GEMM, (hipStream_t)stream, 2.0 * M * N * (double)K * batch,
-                  4.0 * batch * ((double)M * K + (double)N * K + (double)M * N));
     const int64_t big_tiles = (int64_t)((M + 127) / 128) * ((N + 127) / 128) * batch;
+    VhScope scope((vec && big_tiles >= 192) ? VH_FAM_GEMM : VH_FAM_GEMM_SMALL, (hipStream_t)stream, 2.0 * M * N * (double)K * batch,
+                  4.0 * batch * ((double)M * K + (double)N * K + (double)M * N));
+    if (!vec) return launch_gemm<1, 1, 2, 2, 32, false, false>(p, batch, (hipStream_t)stream);
     if (big_tiles >= 192) return launch_gemm<2, 2, 2, 2, 32, false>(p, batch, (hipStream_t)stream);
     return launch_gemm<1, 1, 2, 2, 32, false>(p, batch, (hipStream_t)stream);
 }

@@ -77,7 +77,7 @@ def timing_reset():
 
 def timing_read():
     """-> {family: dict(ms, flops, bytes, launches)} (synchronises the recorded events)"""
-    n = abi_nfam = 8
+    n = abi_nfam = 9
     ms = (ctypes.c_double * n)(); fl = (ctypes.c_double * n)(); by = (ctypes.c_double * n)(); ln = (ctypes.c_int64 * n)()
     lib().so.varhip_timing_read(ms, fl, by, ln)
     return {lib().so.varhip_timing_name(i).decode(): dict(ms=ms[i], flops=fl[i], bytes=by[i], launches=int(ln[i])) for i in range(abi_nfam)}
