@@ -42,7 +42,7 @@ const char* varhip_version(void);
  *                           gamma == NULL means no scaling: resid + (acc + bias)       (basic_vae.py:60,92)
  *   bias may be NULL.  bias_per_row != 0: bias is indexed by m instead of n.
  *   batch >= 1 with element strides sA/sW/sO (sW or sA may be 0 to share an operand); resid/gamma only with batch==1.
- * Fast path: K % 8 == 0, lda/ldw/sA/sW % 4 == 0 and 16-byte aligned A/W; anything else takes an element-wise-load variant. */
+ * Fast path: K % 32 == 0, lda/ldw/sA/sW % 4 == 0 and 16-byte aligned A/W; anything else takes an element-wise-load variant. */
 #define VARHIP_EPI_NONE 0
 #define VARHIP_EPI_GELU 1
 #define VARHIP_EPI_RESID 2

@@ -20,6 +20,7 @@ struct GemmP {
     int M, N, K, epi, rows_per_group, bias_per_row;
     int H, Wd, Cin, up2, out_mode, Hi, Wi;     // convolution only
     int tilesM, tilesN;
+    int evec;                                   // epilogue may use 16-byte accesses (N, leading dims and pointers allow it)
 };
 
 template <int TM, int TN, int WGM, int WGN, int BK, bool CONV, bool VEC>
@@ -100,8 +101,10 @@ __global__ void __launch_bounds__(256) k_mfma_gemm(GemmP p) {
                 src = a_ptr[i] + k0;
             }
             if (VEC) {
-                if (ok) { ra[i][0] = *(const f32x4*)src; ra[i][1] = *(const f32x4*)(src + 4); }
-                else { ra[i][0] = zero4; ra[i][1] = zero4; }
+                // fast path (host guarantees K % BK == 0): the address is always valid (rows/pixels are clamped), so the loads are
+                // unconditional and branch-free; rows >= M only feed outputs that are never stored, conv padding is a select
+                ra[i][0] = *(const f32x4*)src; ra[i][1] = *(const f32x4*)(src + 4);
+                if (CONV && !ok) { ra[i][0] = zero4; ra[i][1] = zero4; }
             } else {            // any K / leading dimension / alignment: element-wise guarded loads (small shapes only)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) ra[i][e >> 2][e & 3] = (ok && k0 + a_c[i] * 8 + e < p.K) ? src[e] : 0.f;
@@ -112,8 +115,7 @@ __global__ void __launch_bounds__(256) k_mfma_gemm(GemmP p) {
             const bool ok = b_ok[i] && (k0 + b_c[i] * 8 < p.K);
             const float* src = b_ptr[i] + k0;
             if (VEC) {
-                if (ok) { rb[i][0] = *(const f32x4*)src; rb[i][1] = *(const f32x4*)(src + 4); }
-                else { rb[i][0] = zero4; rb[i][1] = zero4; }
+                rb[i][0] = *(const f32x4*)src; rb[i][1] = *(const f32x4*)(src + 4);      // rows >= N: clamped, never stored
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) rb[i][e >> 2][e & 3] = (ok && k0 + b_c[i] * 8 + e < p.K) ? src[e] : 0.f;
@@ -162,6 +164,9 @@ __global__ void __launch_bounds__(256) k_mfma_gemm(GemmP p) {
         const float* sB = smem + cur * STAGE + BM * LDSW + (wn * TN * 32 + r) * LDSW + h * 4;
 #pragma unroll
         for (int c = 0; c < CPR; ++c) {
+            // the next tile goes to the other LDS stage in the MIDDLE of this tile's MFMAs (that stage was last read one
+            // iteration ago, a barrier has passed since), so its ds_writes hide under matrix work instead of preceding the barrier
+            if (c == (CPR + 1) / 2 && kt + 1 < nk) store_tile(cur ^ 1);
             f32x4 af[TM], bf[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) af[i] = *(const f32x4*)(sA + i * 32 * LDSW + c * 8);
@@ -175,36 +180,74 @@ __global__ void __launch_bounds__(256) k_mfma_gemm(GemmP p) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_tile(cur ^ 1);
         __syncthreads();
     }
 
-    // ---- epilogue: C/D layout of the 32x32 accumulator: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    // ---- epilogue.  C/D layout of a 32x32 accumulator: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5), i.e. 4 bytes per
+    // lane per row.  Each wave transposes one accumulator at a time through a private LDS patch (the K-loop stages are
+    // free now: the loop ended on a barrier) so that a lane owns 4 consecutive columns of a row: bias / gamma / residual
+    // are read and the result is written with 16-byte accesses, 4x fewer memory instructions than the direct layout.
+    constexpr int EPW = 36;
+    float* ep = smem + wave * (32 * EPW);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int n = n0 + (wn * TN + j) * 32 + r;
-            if (n >= p.N) continue;
-            const float bn = (p.bias && !p.bias_per_row) ? p.bias[n] : 0.f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (m >= p.M) continue;
-                float v = acc[i][j][e];
-                if (p.bias) v = v + (p.bias_per_row ? p.bias[m] : bn);
-                if (p.epi == VARHIP_EPI_GELU) v = vm_gelu_tanh(v);
-                else if (p.epi == VARHIP_EPI_RESID) {
-                    if (p.gamma) v = v * p.gamma[(int64_t)(m / p.rows_per_group) * p.ldg + n];
-                    v = p.resid[(int64_t)m * p.ldr + n] + v;
-                }
-                if (CONV && p.out_mode != 0) {
+            const int tm0 = m0 + (wm * TM + i) * 32, tn0 = n0 + (wn * TN + j) * 32;
+            if (tm0 >= p.M || tn0 >= p.N) continue;                       // wave-uniform
+            if (CONV && p.out_mode != 0) {                                   // last conv: NCHW store of <= 3 channels, direct layout
+                const int n = tn0 + r;
+                if (n < p.N) {
+                    const float bn = p.bias[n];
                     const int hw = p.H * p.Wd;
-                    const int b = m / hw, rem2 = m - b * hw;
-                    v = vm_min(vm_max(v, -1.0f), 1.0f);
-                    Ob[((int64_t)b * p.N + n) * hw + rem2] = p.out_mode == 1 ? (v + 1.0f) * 0.5f : v;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int m = tm0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        if (m >= p.M) continue;
+                        const int b = m / hw, rem2 = m - b * hw;
+                        const float v = vm_min(vm_max(acc[i][j][e] + bn, -1.0f), 1.0f);
+                        Ob[((int64_t)b * p.N + n) * hw + rem2] = p.out_mode == 1 ? (v + 1.0f) * 0.5f : v;
+                    }
+                }
+                continue;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) ep[((e & 3) + 8 * (e >> 2) + 4 * h) * EPW + r] = acc[i][j][e];
+            const int c4 = (lane & 7) * 4, n = tn0 + c4;
+            const bool full = p.evec && (n + 3 < p.N);
+            f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias && !p.bias_per_row) {
+                if (full) b4 = *(const f32x4*)(p.bias + n);
+                else { for (int e = 0; e < 4; ++e) if (n + e < p.N) b4[e] = p.bias[n + e]; }
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = it * 8 + (lane >> 3), m = tm0 + row;
+                f32x4 v = *(const f32x4*)(ep + row * EPW + c4);
+                if (m >= p.M || n >= p.N) continue;
+                if (p.bias) { if (p.bias_per_row) { const float bm = p.bias[m]; v[0] = v[0] + bm; v[1] = v[1] + bm; v[2] = v[2] + bm; v[3] = v[3] + bm; }
+                              else { v[0] = v[0] + b4[0]; v[1] = v[1] + b4[1]; v[2] = v[2] + b4[2]; v[3] = v[3] + b4[3]; } }
+                if (p.epi == VARHIP_EPI_GELU) { v[0] = vm_gelu_tanh(v[0]); v[1] = vm_gelu_tanh(v[1]); v[2] = vm_gelu_tanh(v[2]); v[3] = vm_gelu_tanh(v[3]); }
+                if (full) {
+                    if (p.epi == VARHIP_EPI_RESID) {
+                        if (p.gamma) {
+                            const f32x4 g4 = *(const f32x4*)(p.gamma + (int64_t)(m / p.rows_per_group) * p.ldg + n);
+                            v[0] = v[0] * g4[0]; v[1] = v[1] * g4[1]; v[2] = v[2] * g4[2]; v[3] = v[3] * g4[3];
+                        }
+                        const f32x4 r4 = *(const f32x4*)(p.resid + (int64_t)m * p.ldr + n);
+                        v[0] = r4[0] + v[0]; v[1] = r4[1] + v[1]; v[2] = r4[2] + v[2]; v[3] = r4[3] + v[3];
+                    }
+                    *(f32x4*)(Ob + (int64_t)m * p.ldo + n) = v;
                 } else {
-                    Ob[(int64_t)m * p.ldo + n] = v;
+                    for (int e = 0; e < 4; ++e) {
+                        if (n + e >= p.N) break;
+                        float x = v[e];
+                        if (p.epi == VARHIP_EPI_RESID) {
+                            if (p.gamma) x = x * p.gamma[(int64_t)(m / p.rows_per_group) * p.ldg + n + e];
+                            x = p.resid[(int64_t)m * p.ldr + n + e] + x;
+                        }
+                        Ob[(int64_t)m * p.ldo + n + e] = x;
+                    }
                 }
             }
         }
@@ -232,7 +275,7 @@ extern "C" int varhip_gemm_nt_f32(const float* A, int64_t lda, const float* W, i
                                   const float* resid, int64_t ldr, const float* gamma, int64_t ldg, int rows_per_group,
                                   int bias_per_row, int batch, int64_t sA, int64_t sW, int64_t sO, varhip_stream_t stream) {
     if (M < 0 || N <= 0 || K <= 0 || batch < 1) return VARHIP_EINVAL;
-    const bool vec = !((K & 7) || (lda & 3) || (ldw & 3) || (sA & 3) || (sW & 3) || (((uintptr_t)A | (uintptr_t)W) & 15));
+    const bool vec = !((K & 31) || (lda & 3) || (ldw & 3) || (sA & 3) || (sW & 3) || (((uintptr_t)A | (uintptr_t)W) & 15));
     if (batch > 1 && (resid || gamma)) return VARHIP_EINVAL;
     if (epi < 0 || epi > 2 || (epi == VARHIP_EPI_RESID && !resid)) return VARHIP_EINVAL;
     if (M == 0) return 0;
@@ -240,12 +283,24 @@ extern "C" int varhip_gemm_nt_f32(const float* A, int64_t lda, const float* W, i
     p.A = A; p.W = W; p.bias = bias; p.out = out; p.resid = resid; p.gamma = gamma;
     p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.ldr = ldr; p.ldg = ldg; p.sA = sA; p.sW = sW; p.sO = sO;
     p.M = M; p.N = N; p.K = K; p.epi = epi; p.rows_per_group = rows_per_group > 0 ? rows_per_group : 1; p.bias_per_row = bias_per_row;
-    const int64_t big_tiles = (int64_t)((M + 127) / 128) * ((N + 127) / 128) * batch;
-    VhScope scope((vec && big_tiles >= 192) ? VH_FAM_GEMM : VH_FAM_GEMM_SMALL, (hipStream_t)stream, 2.0 * M * N * (double)K * batch,
+    p.evec = !((N & 3) || (ldo & 3) || (sO & 3) || ((uintptr_t)out & 15) || (bias && !bias_per_row && ((uintptr_t)bias & 15)) ||
+               (resid && ((ldr & 3) || ((uintptr_t)resid & 15))) || (gamma && ((ldg & 3) || ((uintptr_t)gamma & 15))));
+    // Tile choice.  K cannot be split (arithmetic contract), so launches that do not fill 256 CUs several times over pay
+    // for block-count quantisation: cost ~ ceil(blocks / 256 CUs) * tile area / relative tile efficiency; pick the cheapest.
+    auto cost = [&](int bm, int bn, double eff) {
+        const int64_t nb = (int64_t)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch;
+        return (double)((nb + 255) / 256) * bm * bn / eff;
+    };
+    const double c128 = cost(128, 128, 1.0), c12864 = cost(128, 64, 0.93), c64 = cost(64, 64, 0.78);
+    const int pick = !vec ? 3 : (c128 <= c12864 && c128 <= c64) ? 0 : (c12864 <= c64 ? 1 : 2);
+    VhScope scope(pick == 0 ? VH_FAM_GEMM : VH_FAM_GEMM_SMALL, (hipStream_t)stream, 2.0 * M * N * (double)K * batch,
                   4.0 * batch * ((double)M * K + (double)N * K + (double)M * N));
-    if (!vec) return launch_gemm<1, 1, 2, 2, 32, false, false>(p, batch, (hipStream_t)stream);
-    if (big_tiles >= 192) return launch_gemm<2, 2, 2, 2, 32, false>(p, batch, (hipStream_t)stream);
-    return launch_gemm<1, 1, 2, 2, 32, false>(p, batch, (hipStream_t)stream);
+    switch (pick) {
+        case 0: return launch_gemm<2, 2, 2, 2, 32, false>(p, batch, (hipStream_t)stream);
+        case 1: return launch_gemm<2, 1, 2, 2, 32, false>(p, batch, (hipStream_t)stream);
+        case 2: return launch_gemm<1, 1, 2, 2, 32, false>(p, batch, (hipStream_t)stream);
+        default: return launch_gemm<1, 1, 2, 2, 32, false, false>(p, batch, (hipStream_t)stream);
+    }
 }
 
 extern "C" int varhip_conv3x3_nhwc_f32(const float* in, const float* w, const float* bias, const float* resid, float* out,
@@ -259,6 +314,7 @@ extern "C" int varhip_conv3x3_nhwc_f32(const float* in, const float* w, const fl
     p.ldw = 9ll * Cin; p.ldo = Cout; p.ldr = Cout;
     p.M = B * H * W; p.N = Cout; p.K = 9 * Cin; p.epi = resid ? VARHIP_EPI_RESID : VARHIP_EPI_NONE; p.rows_per_group = 1;
     p.H = H; p.Wd = W; p.Cin = Cin; p.up2 = up2; p.out_mode = out_mode; p.Hi = up2 ? H / 2 : H; p.Wi = up2 ? W / 2 : W;
+    p.evec = !((Cout & 3) || ((uintptr_t)out & 15) || ((uintptr_t)bias & 15) || (resid && ((uintptr_t)resid & 15)));
     const double npix = (double)B * H * W;
     VhScope scope(VH_FAM_CONV, (hipStream_t)stream, 2.0 * npix * Cout * 9.0 * Cin,
                   4.0 * (npix * Cin / (up2 ? 4.0 : 1.0) + npix * Cout * (resid ? 2.0 : 1.0) + 9.0 * Cin * Cout));
