@@ -262,7 +262,7 @@ static int launch_gemm(GemmP& p, int batch, hipStream_t stream) {
     auto kfn = k_mfma_gemm<TM, TN, WGM, WGN, BK, CONV, VEC>;
     static bool attr_done = false;
     if (!attr_done) {
-        if (lds > 48 * 1024) hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     dim3 grid(p.tilesM * p.tilesN, 1, batch);

@@ -166,24 +166,33 @@ extern "C" int varhip_softmax_rows_f32(const float* x, float* out, int64_t rows,
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// GroupNorm statistics.  Pass 1: block = (chunk of GN_PIX pixels, sample): per-channel fp64 sum / sum of squares over the
-// chunk, folded to groups -> scratch[b][chunk][g][2].  Pass 2: per (b,g) sum the chunks in order, mean / rstd.
+// GroupNorm (32 groups, channels-last).  Both kernels give every thread one float4 of channels (column q = t % (C/4)) and walk
+// pixels with it, so loads/stores are 16-byte and coalesced and all per-channel constants live in registers.
+// Statistics: pass 1, block = (chunk of GN_PIX pixels, sample): fp64 sum / sum of squares per thread, folded through LDS to
+// the 32 groups -> scratch[b][chunk][g][2]; pass 2 sums the chunks in order.  Fixed order: run-to-run deterministic.
 #define GN_PIX 256
 __global__ void __launch_bounds__(256) k_gn_partial(const float* __restrict__ x, double* __restrict__ scratch, int HW, int C, int G, int nchunk) {
-    extern __shared__ double gsm[];                 // [2][C]
+    extern __shared__ double gsm[];                 // [rows_per_pass][C][2]
     const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int C4 = C >> 2, rpp = 256 / C4, q = tid % C4, prow = tid / C4;
     const int p0 = chunk * GN_PIX, p1 = (p0 + GN_PIX < HW) ? p0 + GN_PIX : HW;
-    for (int c = tid; c < C; c += 256) {
-        double s = 0.0, s2 = 0.0;
-        const float* px = x + ((int64_t)b * HW + p0) * C + c;
-        for (int p = p0; p < p1; ++p, px += C) { const double v = (double)*px; s += v; s2 += v * v; }
-        gsm[c] = s; gsm[C + c] = s2;
+    if (prow < rpp) {
+        double s[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+        const float* px = x + ((int64_t)b * HW + p0 + prow) * C + 4 * q;
+        for (int p = p0 + prow; p < p1; p += rpp, px += (int64_t)rpp * C) {
+            const f32x4 v = *(const f32x4*)px;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const double d = (double)v[e]; s[e] += d; s2[e] += d * d; }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { gsm[((int64_t)prow * C + 4 * q + e) * 2] = s[e]; gsm[((int64_t)prow * C + 4 * q + e) * 2 + 1] = s2[e]; }
     }
     __syncthreads();
     const int cpg = C / G;
     for (int g = tid; g < G; g += 256) {
         double s = 0.0, s2 = 0.0;
-        for (int c = 0; c < cpg; ++c) { s += gsm[g * cpg + c]; s2 += gsm[C + g * cpg + c]; }
+        for (int rr = 0; rr < rpp; ++rr)
+            for (int c = 0; c < cpg; ++c) { s += gsm[((int64_t)rr * C + g * cpg + c) * 2]; s2 += gsm[((int64_t)rr * C + g * cpg + c) * 2 + 1]; }
         double* o = scratch + (((int64_t)b * nchunk + chunk) * G + g) * 2;
         o[0] = s; o[1] = s2;
     }
@@ -205,42 +214,43 @@ extern "C" int64_t varhip_gn_scratch_elems(int B, int HW, int C, int G) {
     return (int64_t)B * ((HW + GN_PIX - 1) / GN_PIX) * G * 2;
 }
 extern "C" int varhip_gn_stats_f32(const float* x, float* stats, double* scratch, int B, int HW, int C, int G, float eps, varhip_stream_t stream) {
-    if (B <= 0 || HW <= 0 || C <= 0 || G <= 0 || (C % G) || !scratch || C > 4096) return VARHIP_EINVAL;
+    if (B <= 0 || HW <= 0 || C <= 0 || G <= 0 || (C % G) || !scratch || (C & 3) || C > 1024 || ((uintptr_t)x & 15)) return VARHIP_EINVAL;
     const int nchunk = (HW + GN_PIX - 1) / GN_PIX;
     VhScope sc(VH_FAM_GN, (hipStream_t)stream, 0, 4.0 * B * (double)HW * C);
-    hipLaunchKernelGGL(k_gn_partial, dim3(nchunk, B), dim3(256), 2 * C * sizeof(double), (hipStream_t)stream, x, scratch, HW, C, G, nchunk);
+    const size_t lds = (size_t)(256 / (C / 4)) * C * 2 * sizeof(double);
+    hipLaunchKernelGGL(k_gn_partial, dim3(nchunk, B), dim3(256), lds, (hipStream_t)stream, x, scratch, HW, C, G, nchunk);
     hipLaunchKernelGGL(k_gn_final, dim3((B * G + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch, stats, B, G, nchunk, (double)HW * (C / G), eps);
     return vh_launch_status();
 }
 
 __global__ void __launch_bounds__(256) k_gn_apply(const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                  const float* __restrict__ beta, float* __restrict__ out, int64_t n4, int HW, int C, int G, int silu) {
-    const int cpg = C / G;
-    const int64_t per_b = (int64_t)HW * C;
-    int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i4 < n4; i4 += stride) {
-        const int64_t i = i4 * 4;
-        const int b = (int)(i / per_b), c0 = (int)(i % C);
-        const f32x4 v = *(const f32x4*)(x + i);
+                                                  const float* __restrict__ beta, float* __restrict__ out, int HW, int C, int G, int silu) {
+    const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int C4 = C >> 2, rpp = 256 / C4, q = tid % C4, prow = tid / C4, cpg = C / G;
+    if (prow >= rpp) return;
+    float mean[4], rstd[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float* st = stats + ((int64_t)b * G + (4 * q + e) / cpg) * 2; mean[e] = st[0]; rstd[e] = st[1]; }
+    const f32x4 g4 = *(const f32x4*)(gamma + 4 * q), b4 = *(const f32x4*)(beta + 4 * q);
+    const int p0 = chunk * GN_PIX, p1 = (p0 + GN_PIX < HW) ? p0 + GN_PIX : HW;
+    int64_t off = ((int64_t)b * HW + p0 + prow) * C + 4 * q;
+    for (int p = p0 + prow; p < p1; p += rpp, off += (int64_t)rpp * C) {
+        const f32x4 v = *(const f32x4*)(x + off);
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int c = c0 + e;
-            const float* st = stats + ((int64_t)b * G + c / cpg) * 2;
-            float y = ((v[e] - st[0]) * st[1]) * gamma[c] + beta[c];
+            const float y = ((v[e] - mean[e]) * rstd[e]) * g4[e] + b4[e];
             o[e] = silu ? vm_silu(y) : y;
         }
-        *(f32x4*)(out + i) = o;
+        *(f32x4*)(out + off) = o;
     }
 }
 extern "C" int varhip_gn_apply_f32(const float* x, const float* stats, const float* gamma, const float* beta, float* out,
                                    int B, int HW, int C, int G, int silu, varhip_stream_t stream) {
-    if (B <= 0 || HW <= 0 || C <= 0 || G <= 0 || (C % G) || (C & 3)) return VARHIP_EINVAL;
-    const int64_t n4 = (int64_t)B * HW * C / 4;
-    VhScope sc(VH_FAM_GN, (hipStream_t)stream, 0, 8.0 * n4 * 4);
-    int64_t blocks = (n4 + 255) / 256; if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(k_gn_apply, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, stats, gamma, beta, out, n4, HW, C, G, silu);
+    if (B <= 0 || HW <= 0 || C <= 0 || G <= 0 || (C % G) || (C & 3) || C > 1024) return VARHIP_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15) return VARHIP_EINVAL;
+    VhScope sc(VH_FAM_GN, (hipStream_t)stream, 0, 8.0 * B * (double)HW * C);
+    hipLaunchKernelGGL(k_gn_apply, dim3((HW + GN_PIX - 1) / GN_PIX, B), dim3(256), 0, (hipStream_t)stream, x, stats, gamma, beta, out, HW, C, G, silu);
     return vh_launch_status();
 }
 

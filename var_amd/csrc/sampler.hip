@@ -17,9 +17,9 @@ __global__ void __launch_bounds__(256) k_cfg_sample(const float* __restrict__ lo
     extern __shared__ __attribute__((aligned(16))) unsigned char sm_raw[];
     float* xs = reinterpret_cast<float*>(sm_raw);                                   // [V] working logits
     unsigned long long* srt = reinterpret_cast<unsigned long long*>(sm_raw + sizeof(float) * V);   // [V] (key<<32 | idx)
-    __shared__ unsigned hist[256];
+    __shared__ int s_ci[8];
     __shared__ float red[4];
-    __shared__ unsigned s_prefix, s_k, s_cnt;
+    __shared__ unsigned s_cnt;
     __shared__ float s_bv[4]; __shared__ int s_bi[4]; __shared__ int s_bn[4];
 
     const int tid = threadIdx.x;
@@ -31,29 +31,22 @@ __global__ void __launch_bounds__(256) k_cfg_sample(const float* __restrict__ lo
     for (int i = tid; i < V; i += 256) { const float a = ca * lc[i]; const float b = cb * lu[i]; xs[i] = a - b; }
     __syncthreads();
 
-    // (2) top-k: find the key of the k-th largest by 4 rounds of 8-bit radix select from the top byte down
+    // (2) top-k: the key of the k-th largest, built bit by bit from the top: T is the largest value with count(key >= T) >= k.
+    // 32 exact integer block reductions, no atomics (a radix histogram serialises on the few populated top-byte bins).
     if (top_k > 0) {
-        if (tid == 0) { s_prefix = 0u; s_k = (unsigned)top_k; }
-        unsigned mask = 0u;
-        for (int pass = 3; pass >= 0; --pass) {
-            hist[tid] = 0u;
+        unsigned T = 0u;
+        for (int bit = 31; bit >= 0; --bit) {
+            const unsigned cand = T | (1u << bit);
+            int cnt = 0;
+            for (int i = tid; i < V; i += 256) cnt += (vm_float_key(xs[i]) >= cand) ? 1 : 0;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+            if ((tid & 63) == 0) s_ci[(bit & 1) * 4 + (tid >> 6)] = cnt;      // two alternating slots: one barrier per round
             __syncthreads();
-            const unsigned prefix = s_prefix;
-            for (int i = tid; i < V; i += 256) {
-                const unsigned key = vm_float_key(xs[i]);
-                if ((key & mask) == prefix) atomicAdd(&hist[(key >> (8 * pass)) & 255u], 1u);
-            }
-            __syncthreads();
-            if (tid == 0) {
-                unsigned k = s_k, bin = 255u;
-                for (;; --bin) { const unsigned c = hist[bin]; if (c >= k || bin == 0u) break; k -= c; }
-                s_k = k; s_prefix = prefix | (bin << (8 * pass));
-            }
-            mask |= 255u << (8 * pass);
-            __syncthreads();
+            const int* c4 = s_ci + (bit & 1) * 4;
+            if (c4[0] + c4[1] + c4[2] + c4[3] >= top_k) T = cand;
         }
-        const unsigned kth = s_prefix;
-        for (int i = tid; i < V; i += 256) if (vm_float_key(xs[i]) < kth) xs[i] = -INFINITY;
+        for (int i = tid; i < V; i += 256) if (vm_float_key(xs[i]) < T) xs[i] = -INFINITY;
         __syncthreads();
     }
 
@@ -92,14 +85,21 @@ __global__ void __launch_bounds__(256) k_cfg_sample(const float* __restrict__ lo
                 __syncthreads();
             }
         }
-        // ascending walk with the fp64 running sum; masked (-inf) entries precede everything and add exactly 0.
-        // The removed set is a prefix of the order (cum is non-decreasing); the last (largest) entry is never removed.
+        // every survivor's probability, in sorted order, replaces the (now useless) key half of its sort entry ...
+        for (int sidx = tid; sidx < cnt; sidx += 256) {
+            const unsigned i = (unsigned)srt[sidx];
+            srt[sidx] = ((unsigned long long)__float_as_uint(vm_exp(xs[i] - m) / S) << 32) | i;
+        }
+        __syncthreads();
+        // ... so that the ascending walk with the fp64 running sum (ATen's cumsum order) is a bare add/compare per entry.
+        // Masked (-inf) entries precede everything and add exactly 0; the removed set is a prefix of the order (cum is
+        // non-decreasing); the last (largest) entry is never removed.
         if (tid == 0) {
             double c = 0.0;
-            for (int s = 0; s < cnt - 1; ++s) {
-                const int i = (int)(unsigned)srt[s];
-                c += (double)(vm_exp(xs[i] - m) / S);
-                if ((float)c <= thr) xs[i] = -INFINITY; else break;
+            for (int sidx = 0; sidx < cnt - 1; ++sidx) {
+                const unsigned long long e = srt[sidx];
+                c += (double)__uint_as_float((unsigned)(e >> 32));
+                if ((float)c <= thr) xs[(unsigned)e] = -INFINITY; else break;
             }
         }
         __syncthreads();

@@ -34,14 +34,14 @@ void vh_timing_begin(int fam, hipStream_t s, double flops, double bytes) {
         g_pool.push_back(r);
     }
     g_pool[g_used].fam = fam;
-    hipEventRecord(g_pool[g_used].a, s);
+    (void)hipEventRecord(g_pool[g_used].a, s);
     g_flops[fam] += flops; g_bytes[fam] += bytes; g_n[fam] += 1;
 }
 
 void vh_timing_end(int fam, hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_mu);
     (void)fam;
-    if (g_used < g_pool.size()) { hipEventRecord(g_pool[g_used].b, s); ++g_used; }
+    if (g_used < g_pool.size()) { (void)hipEventRecord(g_pool[g_used].b, s); ++g_used; }
 }
 
 extern "C" {
