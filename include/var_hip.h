@@ -146,6 +146,9 @@ int varhip_softmax_rows_f32(const float* x, float* out, int64_t rows, int n, flo
 int varhip_nchw_to_nhwc_f32(const float* in, float* out, int B, int C, int HW, varhip_stream_t stream);
 int varhip_nhwc_to_nchw_f32(const float* in, float* out, int B, int C, int HW, varhip_stream_t stream);
 
+/* out[i] = keep[i] ? gt[i] : sampled[i]   — VAR.inpainting's torch.where(mask, gt_tokens, sampled_tokens) (var.py:312-328, fork) */
+int varhip_token_select_i64(const uint8_t* keep, const int64_t* gt, const int64_t* sampled, int64_t* out, int64_t n, varhip_stream_t stream);
+
 /* ---- nearest-codebook lookup (encode side; quant.py:150-157) --------------------------------------------
  * idx[n] = argmin_v ( |z_n|^2 + |e_v|^2 - 2 z_n.e_v ), first index on ties; z: [N][Cv], codebook: [V][Cv] */
 int varhip_nearest_code_f32(const float* z, const float* codebook, int64_t* idx_out, int N, int V, int Cv, varhip_stream_t stream);

@@ -529,6 +529,12 @@ int varref_nhwc_to_nchw_f32(const float* in, float* out, int B, int C, int HW) {
     return 0;
 }
 
+/* torch.where(mask, gt_tokens, sampled_tokens) of VAR.inpainting (var.py:312-328, fork) */
+int varref_token_select_i64(const uint8_t* keep, const int64_t* gt, const int64_t* sampled, int64_t* out, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) out[i] = keep[i] ? gt[i] : sampled[i];
+    return 0;
+}
+
 /* nearest codebook entry (quant.py:155-157): d = |z|^2 + |e|^2 - 2 z.e, argmin, first index on ties */
 int varref_nearest_code_f32(const float* z, const float* codebook, int64_t* idx_out, int N, int V, int Cv) {
     float* ee = (float*)malloc(sizeof(float) * V);

@@ -145,7 +145,8 @@ class OracleVAR:
         return self.linear(cond_silu, f'blocks.{b}.ada_lin.1.weight', self.sd[f'blocks.{b}.ada_lin.1.bias'])
 
     def run(self, labels: Sequence[int], noises: List[np.ndarray], cfg: float, top_k: int, top_p: float,
-            force_idx: Optional[np.ndarray] = None, decode: bool = True, keep_masked: bool = False):
+            force_idx: Optional[np.ndarray] = None, decode: bool = True, keep_masked: bool = False,
+            gt_tokens: Optional[np.ndarray] = None, keep_mask: Optional[np.ndarray] = None):
         """Returns dict(img, idx [B,L], logits [per scale 2B,l,V], f_hat [per scale, NCHW], pooled [per scale, NCHW])."""
         Lf, sd = self.L_, self.sd
         B, C, H, S = len(labels), self.C, self.H, len(self.pns)
@@ -168,6 +169,7 @@ class OracleVAR:
         codebook = self.vd['quantize.embedding.weight']
         out = dict(idx=[], logits=[], f_hat=[], pooled=[], masked=[])
         cur = 0
+        draws = 0          # Exp(1) fills consumed so far (inpainting skips the draw on fully kept scales)
         for si, pn in enumerate(self.pns):                                 # var.py:160
             l = pn * pn
             shared = self.linear(cond_silu, 'shared_ada_lin.1.weight', sd['shared_ada_lin.1.bias']) if self.saln else None   # var.py:165
@@ -189,18 +191,28 @@ class OracleVAR:
                 x = self.linear(hid, f'blocks.{b}.ffn.fc2.weight', sd[f'blocks.{b}.ffn.fc2.bias'], abi.EPI_RESID, resid=x,
                                 gamma=g2, ldg=ada.shape[1], rows_per_group=l)                          # basic_var.py:158
             cur += l
-            # get_logits: AdaLNBeforeHead + head (var.py:118-124, basic_var.py:172-174)
-            hm = self.linear(cond_silu, 'head_nm.ada_lin.1.weight', sd['head_nm.ada_lin.1.bias'])
-            hN = self.ln_mod(x, hm[:, :C], hm[:, C:], l)
-            logits = self.linear(hN, 'head.weight', sd['head.bias'])
-            out['logits'].append(logits.reshape(B2, l, V))
-            idx = np.empty((B * l,), np.int64)
-            masked = np.empty((B * l, V), np.float32) if keep_masked else None
-            t = cfg * (si / (S - 1))                                       # var.py:161,172
-            _ck(Lf['cfg_sample_f32'](_p(logits), _p(f32(noises[si])), _p(idx), _p(masked), B, l, V, float(t), int(top_k), float(top_p)), 'cfg_sample')
-            idx = idx.reshape(B, l)
-            out['idx'].append(idx.copy())
-            if keep_masked: out['masked'].append(masked.reshape(B, l, V))
+            if gt_tokens is not None and bool(np.all(keep_mask[:, cur - l:cur])):
+                # VAR.inpainting, whole scale kept (var.py:312-313): ground-truth tokens, no logits, no RNG draw
+                idx = np.ascontiguousarray(gt_tokens[:, cur - l:cur], dtype=np.int64)
+                out['logits'].append(None); out['idx'].append(idx.copy())
+            else:
+                # get_logits: AdaLNBeforeHead + head (var.py:118-124, basic_var.py:172-174)
+                hm = self.linear(cond_silu, 'head_nm.ada_lin.1.weight', sd['head_nm.ada_lin.1.bias'])
+                hN = self.ln_mod(x, hm[:, :C], hm[:, C:], l)
+                logits = self.linear(hN, 'head.weight', sd['head.bias'])
+                out['logits'].append(logits.reshape(B2, l, V))
+                idx = np.empty((B * l,), np.int64)
+                masked = np.empty((B * l, V), np.float32) if keep_masked else None
+                t = cfg * (si / (S - 1))                                       # var.py:161,172
+                _ck(Lf['cfg_sample_f32'](_p(logits), _p(f32(noises[draws])), _p(idx), _p(masked), B, l, V, float(t), int(top_k), float(top_p)), 'cfg_sample')
+                draws += 1
+                if gt_tokens is not None:                                      # torch.where(mask, gt, sampled): var.py:326-328
+                    km = np.ascontiguousarray(keep_mask[:, cur - l:cur]).astype(np.uint8).reshape(-1)
+                    gs = np.ascontiguousarray(gt_tokens[:, cur - l:cur], dtype=np.int64).reshape(-1)
+                    _ck(Lf['token_select_i64'](_p(km), _p(gs), _p(idx), _p(idx), B * l), 'token_select')
+                idx = idx.reshape(B, l)
+                out['idx'].append(idx.copy())
+                if keep_masked: out['masked'].append(masked.reshape(B, l, V))
             if force_idx is not None:                                      # teacher forcing for drift-free comparison
                 idx = np.ascontiguousarray(force_idx[:, cur - l:cur], dtype=np.int64)
             # quantizer step (var.py:177-183, quant.py:187-196)

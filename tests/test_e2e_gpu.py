@@ -159,6 +159,43 @@ def test_incremental_fhat_equals_embed_to_fhat_and_decoder_api():
     print(m); assert ok, m
 
 
+@pytest.mark.parametrize('name', ['inpaint_t_pn12345', 'inpaint_d16_pn123'])
+def test_inpainting_vs_reference_and_oracle(name, golden_dir):
+    """VAR.inpainting (fork API) on HIP: final tokens identical to the reference's run and to the oracle; kept tokens untouched"""
+    import json
+    from tests.test_oracle_vs_golden import regen_inpaint_noise
+    z = np.load(f'{golden_dir}/{name}.npz')
+    meta = json.loads(str(z['meta']))
+    vae, var = build_models(meta)
+    noise = [torch.from_numpy(n) for n in regen_inpaint_noise(meta, z)]
+    gt, mask = torch.from_numpy(z['gt'].astype(np.int64)).cuda(), torch.from_numpy(z['mask']).cuda()
+    labels = torch.tensor(meta['labels'], device='cuda')
+    img = var.engine().sample(len(meta['labels']), labels, None, meta['cfg'], meta['top_k'], meta['top_p'], noises=noise, trace=True,
+                              gt_tokens=gt, keep_mask=mask)
+    idx = torch.cat(var.engine().last_trace['idx'], dim=1).cpu().numpy()
+    ok, m = util.diff_report(f'{name} tokens vs reference', idx.astype(np.int32), z['idx']); print(m); assert ok, m
+    ok, m = util.diff_report(f'{name} image vs reference', img.cpu().numpy(), z['img'], atol=1e-3); print(m); assert ok, m
+    util.ensure_oracle_built()
+    from oracle.var_oracle import OracleVAR
+    var_sd, vae_sd = util.make_weights(meta)
+    r = OracleVAR(var_sd, vae_sd, meta['patch_nums'], meta['depth']).run(meta['labels'], regen_inpaint_noise(meta, z), meta['cfg'], meta['top_k'],
+                                                                           meta['top_p'], gt_tokens=z['gt'].astype(np.int64), keep_mask=z['mask'])
+    ok, m = util.diff_report(f'{name} tokens vs oracle', idx, r['idx']); print(m); assert ok, m
+    ok, m = util.diff_report(f'{name} f_hat vs oracle (exact)', var.engine().last_trace['f_hat'][-1].cpu().numpy(), r['f_hat'][-1]); print(m); assert ok, m
+    # public API with the device generator: kept tokens are respected, call is deterministic, bad mask shape raises ValueError
+    a = var.inpainting(gt, mask, label=labels, g_seed=3, cfg=meta['cfg'], top_k=meta['top_k'], top_p=meta['top_p'])
+    b = var.inpainting(gt, mask, label=labels, g_seed=3, cfg=meta['cfg'], top_k=meta['top_k'], top_p=meta['top_p'])
+    assert torch.equal(a, b) and a.shape == img.shape
+    full = var.inpainting(gt, torch.ones_like(mask), label=labels, g_seed=3)          # everything kept == decode of gt tokens
+    ms, cur = [], 0
+    for pn in meta['patch_nums']:
+        ms.append(gt[:, cur:cur + pn * pn]); cur += pn * pn
+    ref_img = vae.idxBl_to_img(ms, same_shape=True, last_one=True).add_(1).mul_(0.5)
+    ok, m = util.diff_report('all-kept inpainting == idxBl_to_img', full.cpu().numpy(), ref_img.cpu().numpy(), atol=2e-5); print(m); assert ok, m
+    with pytest.raises(ValueError):
+        var.inpainting(gt, mask[:, :-1], label=labels)
+
+
 def test_d16_batch64_properties():
     """BASELINE.json configs[1] at full size (d16, 10 scales, B=64): determinism and agreement of the first two images with the
     B=2 reference fixture when fed the same noise rows (batch-slice invariance at the headline shape)."""

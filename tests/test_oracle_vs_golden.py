@@ -60,6 +60,33 @@ def test_baseline_config1_d16_pn123():
     _check_case('d16_pn123', logit_atol=5e-4, img_atol=1e-3)
 
 
+def regen_inpaint_noise(meta, z):
+    """the fills VAR.inpainting consumed: one (B*l, V) Exp(1) fill per scale that is not fully kept (reference var.py:312-320)"""
+    import torch
+    g = torch.Generator(); g.manual_seed(meta['seed'])
+    out = []
+    for k, si in enumerate(meta['drawn_scales']):
+        pn = meta['patch_nums'][si]
+        q = torch.empty(meta['B'] * pn * pn, meta['V']).exponential_(1, generator=g)
+        assert np.array_equal(q.view(-1)[:8].numpy(), z['noise_head'][k])
+        out.append(q.numpy())
+    return out
+
+
+@pytest.mark.parametrize('name', ['inpaint_t_pn12345', 'inpaint_d16_pn123'])
+def test_inpainting_cases(name, golden_dir):
+    """VAR.inpainting (fork, var.py:236-364): kept tokens pass through, the rest are resampled; fully kept scales draw no noise"""
+    z = np.load(f'{golden_dir}/{name}.npz')
+    meta = json.loads(str(z['meta']))
+    orc = _oracle(meta)
+    r = orc.run(meta['labels'], regen_inpaint_noise(meta, z), meta['cfg'], meta['top_k'], meta['top_p'],
+                gt_tokens=z['gt'].astype(np.int64), keep_mask=z['mask'])
+    assert np.array_equal(r['idx'].astype(np.int32), z['idx']), f'{name}: final tokens differ in {(r["idx"] != z["idx"]).sum()} places'
+    assert np.array_equal(r['idx'][z['mask']], z['gt'][z['mask']])
+    ok, m = util.diff_report(f'{name} f_hat', r['f_hat'][-1], z['f_hat'], atol=2e-5, rtol=1e-5); print(m); assert ok, m
+    ok, m = util.diff_report(f'{name} image', r['img'], z['img'], atol=1e-4); print(m); assert ok, m
+
+
 def test_sampler_vectors(golden_dir):
     """sample_with_top_k_top_p_ fixtures (helpers.py:6-19): token ids and the kept-set after top-k/top-p must match exactly."""
     z = np.load(f'{golden_dir}/sampler.npz')

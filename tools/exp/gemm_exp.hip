@@ -1,0 +1,229 @@
+// gemm_exp.hip — standalone timing experiments on the fp32 MFMA GEMM main loop (NOT product code; results may be numerically
+// wrong when a stage is ablated).  Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o gemm_exp gemm_exp.hip
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// FLAGS: 1 = skip global loads after the first tile, 2 = skip LDS stores after the first, 4 = skip barrier, 8 = skip LDS reads (reuse regs)
+template <int TM, int TN, int WGM, int WGN, int BK, int FLAGS, int MINW>
+__global__ void __launch_bounds__(256, MINW) k(const float* __restrict__ A, const float* __restrict__ W, float* __restrict__ out, int M, int N, int K) {
+    constexpr int BM = TM * 32 * WGM, BN = TN * 32 * WGN, LDSW = BK + 4, CPR = BK / 8;
+    constexpr int NA = BM * CPR / 256, NB = BN * CPR / 256, STAGE = (BM + BN) * LDSW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int tilesN = N / BN, tilesM = M / BM;
+    int tm_, tn_;
+    {
+        const int nwg = tilesM * tilesN, bid = blockIdx.x;
+        const int q = nwg >> 3, rem = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        const int lin = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + loc;
+        const int GM = 8, width = GM * tilesN, group = lin / width, first = group * GM;
+        const int gsz = (tilesM - first) < GM ? (tilesM - first) : GM;
+        tm_ = first + (lin % width) % gsz; tn_ = (lin % width) / gsz;
+    }
+    const int m0 = tm_ * BM, n0 = tn_ * BN;
+    const float* a_ptr[NA]; const float* b_ptr[NB]; int a_off[NA], b_off[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) { int qq = tid + 256 * i; a_ptr[i] = A + (size_t)(m0 + qq / CPR) * K + (qq % CPR) * 8; a_off[i] = (qq / CPR) * LDSW + (qq % CPR) * 8; }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) { int qq = tid + 256 * i; b_ptr[i] = W + (size_t)(n0 + qq / CPR) * K + (qq % CPR) * 8; b_off[i] = (qq / CPR) * LDSW + (qq % CPR) * 8; }
+    f32x4 ra[NA][2], rb[NB][2];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) { const float* s = a_ptr[i] + kt * BK; ra[i][0] = *(const f32x4*)s; ra[i][1] = *(const f32x4*)(s + 4); }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) { const float* s = b_ptr[i] + kt * BK; rb[i][0] = *(const f32x4*)s; rb[i][1] = *(const f32x4*)(s + 4); }
+    };
+    auto store_tile = [&](int st) {
+        float* sA = smem + st * STAGE; float* sB = sA + BM * LDSW;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) { float* d = sA + a_off[i]; f32x4 ev = {ra[i][0][0], ra[i][0][2], ra[i][1][0], ra[i][1][2]}, od = {ra[i][0][1], ra[i][0][3], ra[i][1][1], ra[i][1][3]}; *(f32x4*)d = ev; *(f32x4*)(d + 4) = od; }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) { float* d = sB + b_off[i]; f32x4 ev = {rb[i][0][0], rb[i][0][2], rb[i][1][0], rb[i][1][2]}, od = {rb[i][0][1], rb[i][0][3], rb[i][1][1], rb[i][1][3]}; *(f32x4*)d = ev; *(f32x4*)(d + 4) = od; }
+    };
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int nk = K / BK;
+    load_tile(0); store_tile(0); store_tile(1); __syncthreads();
+    f32x4 af[TM], bf[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[i] = *(const f32x4*)(smem + (wm * TM * 32 + i * 32 + r) * LDSW + h * 4);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf[j] = *(const f32x4*)(smem + BM * LDSW + (wn * TN * 32 + j * 32 + r) * LDSW + h * 4);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (!(FLAGS & 1) && kt + 1 < nk) load_tile(kt + 1);
+        const float* sA = smem + cur * STAGE + (wm * TM * 32 + r) * LDSW + h * 4;
+        const float* sB = smem + cur * STAGE + BM * LDSW + (wn * TN * 32 + r) * LDSW + h * 4;
+#pragma unroll
+        for (int c = 0; c < CPR; ++c) {
+            if (!(FLAGS & 2) && c == (CPR + 1) / 2 && kt + 1 < nk) store_tile(cur ^ 1);
+            if (!(FLAGS & 8)) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = *(const f32x4*)(sA + i * 32 * LDSW + c * 8);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = *(const f32x4*)(sB + j * 32 * LDSW + c * 8);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+        }
+        if (!(FLAGS & 4)) __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                out[(size_t)(m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * N + n0 + (wn * TN + j) * 32 + r] = acc[i][j][e];
+}
+
+template <int TM, int TN, int WGM, int WGN, int BK, int FLAGS, int MINW>
+void run(const char* name, const float* A, const float* W, float* out, int M, int N, int K) {
+    constexpr int BM = TM * 32 * WGM, BN = TN * 32 * WGN;
+    size_t lds = 2 * (size_t)(BM + BN) * (BK + 4) * 4;
+    auto kf = k<TM, TN, WGM, WGN, BK, FLAGS, MINW>;
+    hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid((M / BM) * (N / BN));
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9;
+    for (int rep = 0; rep < 4; ++rep) {
+        hipEventRecord(e0);
+        for (int it = 0; it < 3; ++it) hipLaunchKernelGGL(kf, grid, dim3(256), lds, 0, A, W, out, M, N, K);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 3; if (ms < best) best = ms;
+    }
+    printf("%-44s %4dx%-4d BK%-2d flags %2d : %8.3f ms  %6.1f TF  (%s)\n", name, BM, BN, BK, FLAGS, best, 2.0 * M * N * K / best / 1e9, hipGetErrorString(hipGetLastError()));
+}
+
+
+// ---- variant B: LDS-DMA staging (global_load_lds 16 B, XOR-swizzled source), MFMA 16x16x4, ds_read_b32 operands, natural k order ----
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <int WT /*wave tile = WT x WT*/, int NSTAGE, int BK, int MINW>
+__global__ void __launch_bounds__(256, MINW) kdma(const float* __restrict__ A, const float* __restrict__ W, float* __restrict__ out, int M, int N, int K) {
+    constexpr int BM = 2 * WT, BN = 2 * WT, T = WT / 16, CH = BK / 4 /*16B chunks per row*/, RPI = 64 / CH /*rows per DMA instr*/;
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // [NSTAGE][(BM+BN)*BK]
+    constexpr int STAGE = (BM + BN) * BK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tilesN = N / BN, tilesM = M / BM;
+    int tm_, tn_;
+    {
+        const int nwg = tilesM * tilesN, bid = blockIdx.x;
+        const int q = nwg >> 3, rem = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        const int lin = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + loc;
+        const int GM = 8, width = GM * tilesN, group = lin / width, first = group * GM;
+        const int gsz = (tilesM - first) < GM ? (tilesM - first) : GM;
+        tm_ = first + (lin % width) % gsz; tn_ = (lin % width) / gsz;
+    }
+    const int m0 = tm_ * BM, n0 = tn_ * BN;
+    // DMA roles: wave w stages rows [w*BM/4, (w+1)*BM/4) of A and the same range of B; one instruction = 8 rows x 128 B
+    constexpr int NI = BM / 4 / RPI;
+    const int drow = lane / CH, dslot = lane % CH;
+    const float* asrc[NI]; const float* bsrc[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int row = wave * (BM / 4) + i * RPI + drow;
+        asrc[i] = A + (size_t)(m0 + row) * K + ((dslot ^ (row & (CH - 1))) << 2);
+        bsrc[i] = W + (size_t)(n0 + row) * K + ((dslot ^ (row & (CH - 1))) << 2);
+    }
+    auto dma_tile = [&](int kt, int st) {
+        float* sA = smem + st * STAGE + wave * (BM / 4) * BK;
+        float* sB = smem + st * STAGE + BM * BK + wave * (BN / 4) * BK;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + kt * BK), (__attribute__((address_space(3))) void*)(sA + i * RPI * BK), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[i] + kt * BK), (__attribute__((address_space(3))) void*)(sB + i * RPI * BK), 16, 0, 0);
+        }
+    };
+    f32x4v acc[T][T];
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < T; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int nk = K / BK;
+    dma_tile(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt % NSTAGE;
+        if (kt + 1 < nk) dma_tile(kt + 1, (kt + 1) % NSTAGE);
+        const float* sA = smem + cur * STAGE + (wm * WT + r16) * BK + kq;
+        const float* sB = smem + cur * STAGE + BM * BK + (wn * WT + r16) * BK + kq;
+#pragma unroll
+        for (int s = 0; s < CH; ++s) {
+            float af[T], bf[T];
+            const int sl = ((s ^ (r16 & (CH - 1))) << 2);        // rows i*16 + r16: (row & 7) == (r16 & 7)
+#pragma unroll
+            for (int i = 0; i < T; ++i) af[i] = sA[i * 16 * BK + sl];
+#pragma unroll
+            for (int j = 0; j < T; ++j) bf[j] = sB[j * 16 * BK + sl];
+#pragma unroll
+            for (int i = 0; i < T; ++i)
+#pragma unroll
+                for (int j = 0; j < T; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < T; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                out[(size_t)(m0 + wm * WT + i * 16 + kq * 4 + e) * N + n0 + wn * WT + j * 16 + r16] = acc[i][j][e];
+}
+
+template <int WT, int NSTAGE, int BK, int MINW>
+void run_dma(const char* name, const float* A, const float* W, float* out, int M, int N, int K, const float* ref) {
+    constexpr int BM = 2 * WT, BN = 2 * WT;
+    size_t lds = (size_t)NSTAGE * (BM + BN) * BK * 4;
+    auto kf = kdma<WT, NSTAGE, BK, MINW>;
+    hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid((M / BM) * (N / BN));
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9;
+    for (int rep = 0; rep < 4; ++rep) {
+        hipEventRecord(e0);
+        for (int it = 0; it < 3; ++it) hipLaunchKernelGGL(kf, grid, dim3(256), lds, 0, A, W, out, M, N, K);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 3; if (ms < best) best = ms;
+    }
+    // bit-compare a sample of outputs with the reference kernel's result
+    std::vector<float> a(4096), b(4096);
+    hipMemcpy(a.data(), out, 4096 * 4, hipMemcpyDeviceToHost); hipMemcpy(b.data(), ref, 4096 * 4, hipMemcpyDeviceToHost);
+    int bad = 0; for (int i = 0; i < 4096; ++i) bad += (a[i] != b[i]);
+    printf("%-44s %4dx%-4d stages %d: %8.3f ms  %6.1f TF  mismatches vs 32x32x2 kernel %d/4096 (%s)\n", name, BM, BN, NSTAGE, best, 2.0 * M * N * K / best / 1e9, bad, hipGetErrorString(hipGetLastError()));
+}
+
+int main(int argc, char** argv) {
+    int M = argc > 1 ? atoi(argv[1]) : 8192, N = argc > 2 ? atoi(argv[2]) : 8192, K = argc > 3 ? atoi(argv[3]) : 4096;
+    float *A, *W, *out;
+    hipMalloc(&A, (size_t)M * K * 4); hipMalloc(&W, (size_t)N * K * 4); hipMalloc(&out, (size_t)M * N * 4);
+    std::vector<float> h((size_t)(M > N ? M : N) * K);
+    for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((double)rand() / RAND_MAX * 2 - 1);
+    hipMemcpy(A, h.data(), (size_t)M * K * 4, hipMemcpyHostToDevice); hipMemcpy(W, h.data(), (size_t)N * K * 4, hipMemcpyHostToDevice);
+    printf("M=%d N=%d K=%d\n", M, N, K);
+    run<2, 2, 2, 2, 32, 0, 1>("baseline 128x128 BK32", A, W, out, M, N, K);
+    float* ref; hipMalloc(&ref, (size_t)M * N * 4);
+    run<2, 2, 2, 2, 32, 0, 1>("baseline again (reference output)", A, W, ref, M, N, K);
+    run_dma<64, 2, 32, 1>("DMA 128x128 BK32 2 stages", A, W, out, M, N, K, ref);
+    run_dma<64, 2, 16, 1>("DMA 128x128 BK16 2 stages", A, W, out, M, N, K, ref);
+    run_dma<64, 2, 16, 4>("DMA 128x128 BK16 2 stages minw4", A, W, out, M, N, K, ref);
+    run_dma<64, 3, 16, 3>("DMA 128x128 BK16 3 stages minw3", A, W, out, M, N, K, ref);
+    run_dma<32, 2, 32, 1>("DMA 64x64 BK32 2 stages", A, W, out, M, N, K, ref);
+    return 0;
+}

@@ -126,6 +126,49 @@ def run_case(name, cfg):
     print(f'[gen_golden] {name}: {dt:.2f}s  img mean {img.mean():.4f}  tokens {rec["idx"].shape}', flush=True)
 
 
+def run_inpaint():
+    """VAR.inpainting fixtures (fork, reference models/var.py:236-364): tokens of an earlier AR run are kept where mask is True.
+    Scales 0-1 fully kept (the reference then skips sampling AND the RNG draw), scale 2 mixed, scale 3 fully resampled, scale 4 mixed."""
+    for name, base in (('inpaint_t_pn12345', 't_pn12345'), ('inpaint_d16_pn123', 'd16_pn123')):
+        cfg = dict(CASES[base])
+        vae, var = build_reference(cfg)
+        z = np.load(os.path.join(GOLD, f'e2e_{base}.npz'))
+        gt = torch.from_numpy(z['idx'].astype(np.int64))
+        B, L = gt.shape
+        g = torch.Generator(); g.manual_seed(11)
+        mask = torch.rand(B, L, generator=g) < 0.5
+        pns = cfg['patch_nums']
+        ends = np.cumsum([p * p for p in pns])
+        begs = np.concatenate([[0], ends[:-1]])
+        mask[:, begs[0]:ends[0]] = True
+        if len(pns) > 3:
+            mask[:, begs[1]:ends[1]] = True
+            mask[:, begs[3]:ends[3]] = False
+        finals, fhats = [], []
+        hk = vae.quantize.embedding.register_forward_hook(lambda m, inp, out: finals.append(inp[0].detach().clone()))
+        orig_next = vae.quantize.get_next_autoregressive_input
+        def get_next(si, SN, f_hat, h):
+            f, nxt = orig_next(si, SN, f_hat, h); fhats.append(f.detach().clone()); return f, nxt
+        vae.quantize.get_next_autoregressive_input = get_next
+        seed = 21
+        with torch.inference_mode():
+            img = var.inpainting(gt, mask, label=torch.tensor(cfg['labels']), g_seed=seed, cfg=cfg['cfg'], top_k=cfg['top_k'], top_p=cfg['top_p'])
+        hk.remove()
+        rec = dict(gt=gt.numpy().astype(np.int32), mask=mask.numpy(), img=img.numpy(), idx=torch.cat(finals, 1).numpy().astype(np.int32),
+                   f_hat=fhats[-1].numpy())
+        # the Exp(1) fills actually consumed: one per scale that is not fully kept, in order
+        gg = torch.Generator(); gg.manual_seed(seed)
+        nh, ns, drawn = [], [], []
+        for si, pn in enumerate(pns):
+            if bool(mask[:, begs[si]:ends[si]].all()): continue
+            q = torch.empty(B * pn * pn, 4096).exponential_(1, generator=gg)
+            nh.append(q.view(-1)[:8].numpy().copy()); ns.append(q.double().sum().item()); drawn.append(si)
+        meta = dict(cfg); meta.update(B=B, V=4096, seed=seed, base=base, drawn_scales=drawn)
+        rec.update(noise_head=np.stack(nh), noise_sum=np.array(ns), meta=np.array(json.dumps(meta)))
+        np.savez_compressed(os.path.join(GOLD, f'{name}.npz'), **rec)
+        print(f'[gen_golden] {name}: kept {int(mask.sum())}/{mask.numel()} tokens, {int((rec["idx"] != rec["gt"]).sum())} resampled differently', flush=True)
+
+
 def run_nearest_code():
     """A17 fixture: VectorQuantizer2.f_to_idxBl_or_fhat (reference models/quant.py:135-166) on a random feature map."""
     cfg = CASES['t_pn12345']
@@ -179,6 +222,7 @@ def main():
     for name, cfg in CASES.items():
         if args.only and name not in args.only: continue
         run_case(name, cfg)
+    if not args.only or 'inpaint' in args.only: run_inpaint()
     if not args.only or 'nearest_code' in args.only: run_nearest_code()
     if not args.only or 'sampler' in args.only: run_sampler_vectors()
 

@@ -101,6 +101,18 @@ extern "C" int varhip_next_map_f32(const float* f_hat, const float* word_w, cons
     return vh_launch_status();
 }
 
+__global__ void k_token_select(const uint8_t* __restrict__ keep, const int64_t* __restrict__ gt, const int64_t* __restrict__ sampled, int64_t* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = keep[i] ? gt[i] : sampled[i];
+}
+extern "C" int varhip_token_select_i64(const uint8_t* keep, const int64_t* gt, const int64_t* sampled, int64_t* out, int64_t n, varhip_stream_t stream) {
+    if (n < 0) return VARHIP_EINVAL;
+    if (n == 0) return 0;
+    VhScope sc(VH_FAM_OTHER, (hipStream_t)stream, 0, 25.0 * n);
+    hipLaunchKernelGGL(k_token_select, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, keep, gt, sampled, out, n);
+    return vh_launch_status();
+}
+
 // nearest code: one workgroup per z row; thread t scores codes t, t+256, ...; (distance, index) min with first-index ties
 __global__ void __launch_bounds__(256) k_nearest_code(const float* __restrict__ z, const float* __restrict__ codebook, int64_t* __restrict__ idx_out, int V, int Cv) {
     __shared__ float sz[64];

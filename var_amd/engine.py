@@ -246,10 +246,13 @@ class SamplingEngine:
     @torch.no_grad()
     def sample(self, B: int, label_B: torch.Tensor, rng: Optional[torch.Generator], cfg: float, top_k: int, top_p: float,
                noises=None, force_idx: Optional[torch.Tensor] = None, trace: bool = False,
-               decode: bool = True) -> torch.Tensor:
+               decode: bool = True, gt_tokens: Optional[torch.Tensor] = None, keep_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         """label_B: int64 [B] on the device.  noises: optional per-scale Exp(1) tensors [B*l, V] — a list, or a callable
-        (si, l) -> tensor (tests inject the CPU generator's stream; var_amd.multi hands each rank its rows); by default they are drawn with `exponential_(generator=rng)` exactly as torch.multinomial
-        (helpers.py:19) would.  force_idx/trace are test hooks (teacher forcing; keep per-scale logits/tokens/f_hat)."""
+        (si, l) -> tensor (tests inject the CPU generator's stream; var_amd.multi hands each rank its rows); by default they
+        are drawn with `exponential_(generator=rng)` exactly as torch.multinomial (helpers.py:19) would.
+        gt_tokens/keep_mask [B, L]: VAR.inpainting (var.py:236-364, fork) — kept positions take the given token, the others are
+        sampled; a scale whose tokens are all kept skips the head, the sampler and the RNG draw, as the reference does.
+        force_idx/trace are test hooks (teacher forcing; keep per-scale logits/tokens/f_hat)."""
         var = self.var
         self.refresh()
         w, ws = self.w, self.workspace(B)
@@ -262,6 +265,17 @@ class SamplingEngine:
             raise ValueError(f'labels must lie in [0, {var.num_classes}]')
         label_B = label_B.to(dev).contiguous()
         tr = dict(logits=[], idx=[], f_hat=[], pooled=[]) if trace else None
+        gt = keep_u8 = skip = None
+        draws = 0
+        if gt_tokens is not None:
+            if keep_mask is None or tuple(keep_mask.shape) != tuple(gt_tokens.shape) or tuple(gt_tokens.shape) != (B, var.L):
+                raise ValueError('Mask shape must match the latent token shape obtained from vae.img_to_idxBl')
+            gt = gt_tokens.to(dev, torch.int64).contiguous()
+            if int(gt.min()) < 0 or int(gt.max()) >= V:
+                raise ValueError(f'gt_tokens must lie in [0, {V})')
+            keep = keep_mask.to(dev).bool()
+            keep_u8 = keep.to(torch.uint8).contiguous()
+            skip = torch.stack([keep[:, b0:e0].all() for b0, e0 in var.begin_ends]).tolist()      # one host sync for all scales
 
         # prologue (var.py:151-157)
         hip.call('lvl_pos_f32', w['lvl_embed'], w['lvl_1L'], w['pos_1LC'], ws['lvl_pos'], var.L, C)
@@ -296,20 +310,28 @@ class SamplingEngine:
                 self.gemm(ws['xn'], blk['fc1_w'], blk['fc1_b'], ws['hid'], M, EPI_GELU)
                 self.gemm(ws['hid'], blk['fc2_w'], blk['fc2_b'], x, M, EPI_RESID, resid=x2, gamma=g2, ldg=6 * C, rpg=l)
             cur += l
-            # get_logits (var.py:118-124): AdaLNBeforeHead + head
-            hn = ws['hn']
-            hip.call('ln_modulate_f32', x, hn, 2 * C, hn[:, C:], 2 * C, ws['xn'], M, C, l, var.norm_eps)
-            self.gemm(ws['xn'], w['head_w'], w['head_b'], ws['logits'], M)
-            if trace: tr['logits'].append(ws['logits'][:M].view(B2, l, V).clone())
-            # CFG + top-k/top-p + multinomial (var.py:172-175)
-            if noises is not None:
-                noise = (noises(si, l) if callable(noises) else noises[si]).to(dev, torch.float32).contiguous()
+            if skip is not None and skip[si]:
+                # inpainting, every token of this scale is kept: no head, no sampling, no RNG draw (var.py:312-313, fork)
+                idx = gt[:, cur - l:cur].contiguous().view(-1)
+                if trace: tr['logits'].append(None); tr['idx'].append(idx.view(B, l).clone())
             else:
-                noise = torch.empty(B * l, V, dtype=torch.float32, device=dev).exponential_(1, generator=rng)
-            t = cfg * (si / var.num_stages_minus_1) if var.num_stages_minus_1 > 0 else 0.0
-            idx = ws['idx'][:B * l]
-            hip.call('cfg_sample_f32', ws['logits'], noise, idx, None, B, l, V, float(t), int(top_k), float(top_p))
-            if trace: tr['idx'].append(idx.view(B, l).clone())
+                # get_logits (var.py:118-124): AdaLNBeforeHead + head
+                hn = ws['hn']
+                hip.call('ln_modulate_f32', x, hn, 2 * C, hn[:, C:], 2 * C, ws['xn'], M, C, l, var.norm_eps)
+                self.gemm(ws['xn'], w['head_w'], w['head_b'], ws['logits'], M)
+                if trace: tr['logits'].append(ws['logits'][:M].view(B2, l, V).clone())
+                # CFG + top-k/top-p + multinomial (var.py:172-175)
+                if noises is not None:        # a list is indexed by draw count: skipped (fully kept) scales draw nothing
+                    noise = (noises(si, l) if callable(noises) else noises[draws]).to(dev, torch.float32).contiguous()
+                    draws += 1
+                else:
+                    noise = torch.empty(B * l, V, dtype=torch.float32, device=dev).exponential_(1, generator=rng)
+                t = cfg * (si / var.num_stages_minus_1) if var.num_stages_minus_1 > 0 else 0.0
+                idx = ws['idx'][:B * l]
+                hip.call('cfg_sample_f32', ws['logits'], noise, idx, None, B, l, V, float(t), int(top_k), float(top_p))
+                if gt is not None:                                        # torch.where(mask, gt_tokens, sampled) (var.py:326-328)
+                    hip.call('token_select_i64', keep_u8[:, cur - l:cur].contiguous(), gt[:, cur - l:cur].contiguous(), idx, idx, B * l)
+                if trace: tr['idx'].append(idx.view(B, l).clone())
             if force_idx is not None:
                 idx = force_idx[:, cur - l:cur].to(dev, torch.int64).contiguous().view(-1)
             # quantizer step (var.py:177-183)

@@ -129,8 +129,27 @@ class VAR(nn.Module):
             x[0, 0, 0] += self.word_embed.weight[0, 0] * 0 + self.word_embed.bias[0] * 0
         return x
 
-    def inpainting(self, *args, **kwargs):
-        raise NotImplementedError('VAR.inpainting (fork, reference var.py:236-364) is "next" row 1 of SURVEY.md §8(f)')
+    @torch.no_grad()
+    def inpainting(self, gt_tokens: torch.Tensor, mask: torch.Tensor, label: Optional[Union[int, torch.LongTensor]] = None,
+                   g_seed: Optional[int] = None, cfg: float = 1.5, top_k: int = 0, top_p: float = 0.0, more_smooth: bool = False) -> torch.Tensor:
+        """Fork API (reference var.py:236-364): resample the tokens where `mask` is False, keep `gt_tokens` where it is True;
+        gt_tokens/mask are (B, L) as produced by vae.img_to_idxBl (concatenated).  Returns (B, 3, H, W) in [0, 1].
+        Runs the same HIP loop as autoregressive_infer_cfg with the token replacement fused in (SamplingEngine.sample)."""
+        if mask.shape != gt_tokens.shape:
+            raise ValueError('Mask shape must match the latent token shape obtained from vae.img_to_idxBl')
+        if more_smooth:
+            raise NotImplementedError('more_smooth (gumbel) sampling is a "next" row of SURVEY.md §8(f)')
+        dev = self.lvl_1L.device
+        if dev.type != 'cuda':
+            raise RuntimeError('VAR.inpainting: this build runs the sampling loop on MI355X HIP kernels only (no CPU fallback by design)')
+        B = gt_tokens.shape[0]
+        if label is None:
+            label = torch.multinomial(self.uniform_prob, num_samples=B, replacement=True).reshape(B)     # unseeded, as in the reference
+        elif isinstance(label, int):
+            label = torch.full((B,), fill_value=label, device=dev)
+        if g_seed is None: rng = None
+        else: self.rng.manual_seed(g_seed); rng = self.rng
+        return self.engine().sample(B, label.to(dev).long(), rng, cfg, top_k, top_p, gt_tokens=gt_tokens, keep_mask=mask)
 
     def smooth_sampling(self, *args, **kwargs):
         raise NotImplementedError('VAR.smooth_sampling (fork, reference var.py:366-575) is "next" row 4 of SURVEY.md §8(f)')
