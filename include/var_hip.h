@@ -104,6 +104,15 @@ int varhip_quant_accum_f32(const int64_t* idx, const float* codebook, const int3
                            const float* phi_w, const float* phi_b, float ratio,
                            float* up, float* f_hat, int B, int pn, int P, int Cv, varhip_stream_t stream);
 
+/* Same step with the scale's embeddings given directly, h: [B][pn*pn][Cv] (more_smooth: gumbel-softmax @ codebook, var.py:178-182) */
+int varhip_quant_accum_h_f32(const float* h, const int32_t* tap_idx, const float* tap_w,
+                             const float* phi_w, const float* phi_b, float ratio,
+                             float* up, float* f_hat, int B, int pn, int P, int Cv, varhip_stream_t stream);
+
+/* y[r][:] = softmax((x[r][:] * mul + (-ln noise[r][:])) / tau)   — gumbel_softmax_with_rng(logits.mul(1+ratio), tau, hard=False, rng)
+ * (helpers.py:22-36, var.py:179-180); x are the top-k/top-p filtered CFG logits (-inf entries give probability 0). V % 256 == 0. */
+int varhip_gumbel_softmax_f32(const float* x, const float* noise, float* y, int64_t rows, int V, float mul, float tau, varhip_stream_t stream);
+
 /* (4) next-scale input: pooled = adaptive_avg_pool(f_hat -> pq x pq)  (quant.py:192, F.interpolate 'area');
  *     x[b][t][:] = x[b+B][t][:] = word_w[C][Cv] . pooled[b][t][:] + word_b + lvl_pos[t][:]     (var.py:185-187)
  * lvl_pos must already point at row cur_L.  pooled: caller-provided [B][pq*pq][Cv] buffer (intermediate; kept for inspection). */

@@ -46,6 +46,34 @@ VM_FN float vm_exp(float x) {
     return y * s.f;
 }
 
+/* ln(x) for x > 0, relative error ~1 ulp (Cephes logf), from integer exponent extraction + fma polynomial only; x <= 0 or
+ * subnormal -> -inf, NaN -> NaN, +inf -> +inf.  Used by the gumbel noise -log(Exp(1)) of the more_smooth path (helpers.py:26). */
+VM_FN float vm_log(float x) {
+    union { float f; uint32_t u; } c;
+    c.f = x;
+    if (x != x) return x;
+    if (!(x >= 1.17549435e-38f)) { c.u = 0xff800000u; return c.f; }
+    if (c.u == 0x7f800000u) return x;
+    float fe = (float)((int32_t)(c.u >> 23) - 126);
+    c.u = (c.u & 0x007fffffu) | 0x3f000000u;            /* mantissa in [0.5, 1) */
+    float m = c.f;
+    if (m < 0.707106781186547524f) { fe = fe - 1.0f; m = (m + m) - 1.0f; } else { m = m - 1.0f; }
+    const float z = m * m;
+    float p = 7.0376836292e-2f;
+    p = vm_fma(p, m, -1.1514610310e-1f);
+    p = vm_fma(p, m, 1.1676998740e-1f);
+    p = vm_fma(p, m, -1.2420140846e-1f);
+    p = vm_fma(p, m, 1.4249322787e-1f);
+    p = vm_fma(p, m, -1.6668057665e-1f);
+    p = vm_fma(p, m, 2.0000714765e-1f);
+    p = vm_fma(p, m, -2.4999993993e-1f);
+    p = vm_fma(p, m, 3.3333331174e-1f);
+    float y = (p * m) * z;
+    y = vm_fma(-2.12194440e-4f, fe, y);
+    y = vm_fma(-0.5f, z, y);
+    return vm_fma(0.693359375f, fe, m + y);
+}
+
 /* x * sigmoid(x)  (reference: nn.SiLU, basic_var.py:147,170; basic_vae.py:14-15) */
 VM_FN float vm_silu(float x) { return x / (1.0f + vm_exp(-x)); }
 

@@ -363,6 +363,39 @@ int varref_quant_accum_f32(const int64_t* idx, const float* codebook, const int3
     return 0;
 }
 
+/* the same step fed with embeddings instead of token ids (more_smooth path, var.py:178-182): h [B][pn*pn][Cv] acts as a
+ * per-call codebook addressed by the identity */
+int varref_quant_accum_h_f32(const float* h, const int32_t* tap_idx, const float* tap_w, const float* phi_w, const float* phi_b, float ratio,
+                             float* up, float* f_hat, int B, int pn, int P, int Cv) {
+    int64_t n = (int64_t)B * pn * pn;
+    int64_t* ident = (int64_t*)malloc(sizeof(int64_t) * n);
+    for (int64_t i = 0; i < n; ++i) ident[i] = i;
+    int rc = varref_quant_accum_f32(ident, h, tap_idx, tap_w, phi_w, phi_b, ratio, up, f_hat, B, pn, P, Cv);
+    free(ident);
+    return rc;
+}
+
+/* gumbel_softmax_with_rng(logits * mul, tau, hard=False, rng) (helpers.py:22-36): gumbels = -log(Exp(1) noise);
+ * y = softmax((x*mul + g) / tau) with the canonical W256 row sum */
+int varref_gumbel_softmax_f32(const float* x, const float* noise, float* y, int64_t rows, int V, float mul, float tau) {
+    if (V <= 0 || (V & 255)) return VARHIP_EINVAL;
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < rows; ++r) {
+        float* z = (float*)malloc(sizeof(float) * V);
+        float m = -INFINITY;
+        for (int i = 0; i < V; ++i) {
+            float g = -vm_log(noise[r * V + i]);
+            z[i] = (x[r * V + i] * mul + g) / tau;
+            m = vm_max(m, z[i]);
+        }
+        for (int i = 0; i < V; ++i) z[i] = vm_exp(z[i] - m);
+        float S = canon_sum256(z, V);
+        for (int i = 0; i < V; ++i) y[r * V + i] = z[i] / S;
+        free(z);
+    }
+    return 0;
+}
+
 /* area-downsample to the next scale + word_embed + level/position embedding, duplicated for CFG (quant.py:192; var.py:185-187) */
 int varref_next_map_f32(const float* f_hat, const float* word_w, const float* word_b, const float* lvl_pos,
                         float* x_out, float* pooled, int B, int P, int pq, int C, int Cv) {

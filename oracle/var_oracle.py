@@ -146,7 +146,8 @@ class OracleVAR:
 
     def run(self, labels: Sequence[int], noises: List[np.ndarray], cfg: float, top_k: int, top_p: float,
             force_idx: Optional[np.ndarray] = None, decode: bool = True, keep_masked: bool = False,
-            gt_tokens: Optional[np.ndarray] = None, keep_mask: Optional[np.ndarray] = None):
+            gt_tokens: Optional[np.ndarray] = None, keep_mask: Optional[np.ndarray] = None,
+            more_smooth: bool = False, gumbel_noises: Optional[List[np.ndarray]] = None):
         """Returns dict(img, idx [B,L], logits [per scale 2B,l,V], f_hat [per scale, NCHW], pooled [per scale, NCHW])."""
         Lf, sd = self.L_, self.sd
         B, C, H, S = len(labels), self.C, self.H, len(self.pns)
@@ -202,7 +203,7 @@ class OracleVAR:
                 logits = self.linear(hN, 'head.weight', sd['head.bias'])
                 out['logits'].append(logits.reshape(B2, l, V))
                 idx = np.empty((B * l,), np.int64)
-                masked = np.empty((B * l, V), np.float32) if keep_masked else None
+                masked = np.empty((B * l, V), np.float32) if (keep_masked or more_smooth) else None
                 t = cfg * (si / (S - 1))                                       # var.py:161,172
                 _ck(Lf['cfg_sample_f32'](_p(logits), _p(f32(noises[draws])), _p(idx), _p(masked), B, l, V, float(t), int(top_k), float(top_p)), 'cfg_sample')
                 draws += 1
@@ -220,8 +221,18 @@ class OracleVAR:
             else: ti, tw = None, None
             k = phi_index(si, S, self.K_phi)
             pw = np.ascontiguousarray(self.vd[f'quantize.quant_resi.qresi_ls.{k}.weight'].transpose(0, 2, 3, 1))
-            _ck(Lf['quant_accum_f32'](_p(idx), _p(codebook), _p(ti), _p(tw), _p(pw), _p(self.vd[f'quantize.quant_resi.qresi_ls.{k}.bias']),
-                                      self.ratio, _p(up), _p(f_hat), B, pn, P, Cv), 'quant_accum')
+            if more_smooth:                                                # var.py:178-180: gumbel softmax of the FILTERED logits @ codebook
+                r_ = si / (S - 1)
+                gum_t = max(0.27 * (1 - r_ * 0.95), 0.005)
+                probs = np.empty((B * l, V), np.float32)
+                _ck(Lf['gumbel_softmax_f32'](_p(masked), _p(f32(gumbel_noises[si])), _p(probs), B * l, V, float(1 + r_), float(gum_t)), 'gumbel_softmax')
+                h = self.linear(probs, 'vae:codebook_T', None, w=np.ascontiguousarray(codebook.T))
+                out.setdefault('h', []).append(h.reshape(B, l, Cv).copy())
+                _ck(Lf['quant_accum_h_f32'](_p(h), _p(ti), _p(tw), _p(pw), _p(self.vd[f'quantize.quant_resi.qresi_ls.{k}.bias']),
+                                            self.ratio, _p(up), _p(f_hat), B, pn, P, Cv), 'quant_accum_h')
+            else:
+                _ck(Lf['quant_accum_f32'](_p(idx), _p(codebook), _p(ti), _p(tw), _p(pw), _p(self.vd[f'quantize.quant_resi.qresi_ls.{k}.bias']),
+                                          self.ratio, _p(up), _p(f_hat), B, pn, P, Cv), 'quant_accum')
             out['f_hat'].append(f_hat.transpose(0, 3, 1, 2).copy())
             if si != S - 1:
                 pq = self.pns[si + 1]

@@ -196,6 +196,33 @@ def test_inpainting_vs_reference_and_oracle(name, golden_dir):
         var.inpainting(gt, mask[:, :-1], label=labels)
 
 
+def test_more_smooth_vs_oracle_and_reference(golden_dir):
+    """more_smooth=True (gumbel-softmax embeddings): HIP == oracle bit for bit (same vm_log/vm_exp, same sums); vs the reference
+    fixture within the 1/tau-amplified tolerance of tests/test_oracle_vs_golden.py::test_more_smooth_case"""
+    import json
+    from tests.test_oracle_vs_golden import regen_smooth_noise
+    z = np.load(f'{golden_dir}/more_smooth_t_pn12345.npz')
+    meta = json.loads(str(z['meta']))
+    vae, var = build_models(meta)
+    n1, n2 = regen_smooth_noise(meta, z)
+    labels = torch.tensor(meta['labels'], device='cuda')
+    img = var.engine().sample(len(meta['labels']), labels, None, meta['cfg'], meta['top_k'], meta['top_p'], noises=[torch.from_numpy(a) for a in n1],
+                              trace=True, more_smooth=True, gumbel_noises=[torch.from_numpy(a) for a in n2])
+    f_hat = var.engine().last_trace['f_hat'][-1].cpu().numpy()
+    util.ensure_oracle_built()
+    from oracle.var_oracle import OracleVAR
+    var_sd, vae_sd = util.make_weights(meta)
+    r = OracleVAR(var_sd, vae_sd, meta['patch_nums'], meta['depth']).run(meta['labels'], n1, meta['cfg'], meta['top_k'], meta['top_p'],
+                                                                           more_smooth=True, gumbel_noises=n2)
+    ok, m = util.diff_report('more_smooth f_hat vs oracle (exact)', f_hat, r['f_hat'][-1]); print(m); assert ok, m
+    ok, m = util.diff_report('more_smooth image vs oracle', img.cpu().numpy(), r['img'], atol=1e-5); print(m); assert ok, m
+    ok, m = util.diff_report('more_smooth image vs reference', img.cpu().numpy(), z['img'], atol=2e-3); print(m); assert ok, m
+    a = var.autoregressive_infer_cfg(2, labels, g_seed=4, cfg=1.5, top_k=900, top_p=0.96, more_smooth=True)
+    b = var.autoregressive_infer_cfg(2, labels, g_seed=4, cfg=1.5, top_k=900, top_p=0.96, more_smooth=True)
+    c = var.autoregressive_infer_cfg(2, labels, g_seed=4, cfg=1.5, top_k=900, top_p=0.96, more_smooth=False)
+    assert torch.equal(a, b) and not torch.equal(a, c) and torch.isfinite(a).all()
+
+
 def test_d16_batch64_properties():
     """BASELINE.json configs[1] at full size (d16, 10 scales, B=64): determinism and agreement of the first two images with the
     B=2 reference fixture when fed the same noise rows (batch-slice invariance at the headline shape)."""

@@ -193,6 +193,30 @@ def test_quant_step_exact(B, pn, P):
     check(f'next_map pooled P={P}->{pq}', gp, wp); check('next_map x', gx, wx)
 
 
+def test_gumbel_softmax_quant_h_and_token_select_exact():
+    """more_smooth / inpainting helpers: gumbel softmax (shared vm_log), quantizer step from embeddings, token select"""
+    from oracle.var_oracle import bicubic_taps
+    rng = np.random.default_rng(77)
+    rows, V = 12, 4096
+    x = rnd(rng, rows, V, scale=3.0); x[:, ::3] = -np.inf                    # filtered logits: a third masked
+    noise = rng.exponential(1.0, (rows, V)).astype(np.float32); noise[0, 1] = 1e-30; noise[0, 5] = 80.0
+    for mul, tau in ((1.0, 0.27), (1.5, 0.14), (2.0, 0.0135)):
+        y = np.zeros_like(x)
+        (g,), (w,) = both('gumbel_softmax_f32', [x, noise, y, rows, V, mul, tau], [2]); check(f'gumbel softmax tau={tau}', g, w)
+        assert abs(float(w.sum(1).max()) - 1) < 1e-4
+    B, pn, P, Cv = 2, 5, 16, 32
+    h = rnd(rng, B, pn * pn, Cv); pw = rnd(rng, Cv, 3, 3, Cv, scale=0.1); pb = rnd(rng, Cv, scale=0.05)
+    f_hat = rnd(rng, B, P, P, Cv); up = np.zeros_like(f_hat)
+    ti, tw = bicubic_taps(pn, P)
+    (gu, gf), (wu, wf) = both('quant_accum_h_f32', [h, ti, tw, pw, pb, 0.5, up, f_hat, B, pn, P, Cv], [6, 7])
+    check('quant_accum_h up', gu, wu); check('quant_accum_h f_hat', gf, wf)
+    n = 1000
+    keep = (rng.random(n) < 0.4).astype(np.uint8); gt = rng.integers(0, 4096, n).astype(np.int64); sm = rng.integers(0, 4096, n).astype(np.int64)
+    out = np.zeros(n, np.int64)
+    (g,), (w,) = both('token_select_i64', [keep, gt, sm, out, n], [3]); check('token_select', g, w)
+    assert np.array_equal(w, np.where(keep.astype(bool), gt, sm))
+
+
 def test_prologue_and_small_ops_exact():
     rng = np.random.default_rng(3)
     B, C, L, S = 3, 128, 14, 3

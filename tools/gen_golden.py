@@ -169,6 +169,32 @@ def run_inpaint():
         print(f'[gen_golden] {name}: kept {int(mask.sum())}/{mask.numel()} tokens, {int((rec["idx"] != rec["gt"]).sum())} resampled differently', flush=True)
 
 
+def run_more_smooth():
+    """autoregressive_infer_cfg(more_smooth=True) (var.py:178-180, helpers.py:22-36): the embeddings come from a gumbel-softmax
+    over the FILTERED logits (sample_with_top_k_top_p_ mutates them in place) times the codebook; two Exp(1) fills per scale."""
+    cfg = dict(CASES['t_pn12345']); cfg['seed'] = 9
+    vae, var = build_reference(cfg)
+    B = len(cfg['labels'])
+    hs, fhats = [], []
+    orig_next = vae.quantize.get_next_autoregressive_input
+    def get_next(si, SN, f_hat, h):
+        hs.append(h.detach().clone()); f, nxt = orig_next(si, SN, f_hat, h); fhats.append(f.detach().clone()); return f, nxt
+    vae.quantize.get_next_autoregressive_input = get_next
+    with torch.inference_mode():
+        img = var.autoregressive_infer_cfg(B, torch.tensor(cfg['labels']), g_seed=cfg['seed'], cfg=cfg['cfg'], top_k=cfg['top_k'], top_p=cfg['top_p'], more_smooth=True)
+    rec = dict(img=img.numpy(), f_hat=fhats[-1].numpy())
+    for si, h in enumerate(hs): rec[f'h_s{si}'] = h.numpy()            # (B, Cvae, pn, pn)
+    g = torch.Generator(); g.manual_seed(cfg['seed'])
+    heads = []
+    for pn in cfg['patch_nums']:
+        a = torch.empty(B * pn * pn, 4096).exponential_(1, generator=g); b = torch.empty(B, pn * pn, 4096).exponential_(generator=g)
+        heads.append(np.concatenate([a.view(-1)[:4].numpy(), b.view(-1)[:4].numpy()]))
+    meta = dict(cfg); meta.update(B=B, V=4096)
+    rec.update(noise_head=np.stack(heads), meta=np.array(json.dumps(meta)))
+    np.savez_compressed(os.path.join(GOLD, 'more_smooth_t_pn12345.npz'), **rec)
+    print(f'[gen_golden] more_smooth_t_pn12345: img mean {img.mean():.4f}', flush=True)
+
+
 def run_nearest_code():
     """A17 fixture: VectorQuantizer2.f_to_idxBl_or_fhat (reference models/quant.py:135-166) on a random feature map."""
     cfg = CASES['t_pn12345']
@@ -223,6 +249,7 @@ def main():
         if args.only and name not in args.only: continue
         run_case(name, cfg)
     if not args.only or 'inpaint' in args.only: run_inpaint()
+    if not args.only or 'more_smooth' in args.only: run_more_smooth()
     if not args.only or 'nearest_code' in args.only: run_nearest_code()
     if not args.only or 'sampler' in args.only: run_sampler_vectors()
 

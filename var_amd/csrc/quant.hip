@@ -6,23 +6,26 @@
 // the oracle's order; what matters is that the whole step is 4 launches instead of the reference's ~15 ATen calls.
 #include "common.h"
 
+// FROM_H: `codebook` is the scale's embedding map h [B][pn*pn][Cv] itself and row ids are the identity (more_smooth path)
+template <bool FROM_H>
 __global__ void k_gather_up(const int64_t* __restrict__ idx, const float* __restrict__ codebook, const int32_t* __restrict__ tap_idx,
                             const float* __restrict__ tap_w, float* __restrict__ up, int B, int pn, int P, int Cv) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // [B][P][P][Cv]
     if (i >= (int64_t)B * P * P * Cv) return;
     const int c = (int)(i % Cv); int64_t t = i / Cv; const int x = (int)(t % P); t /= P; const int y = (int)(t % P); const int b = (int)(t / P);
-    const int64_t* ib = idx + (int64_t)b * pn * pn;
-    if (pn == P) { up[i] = codebook[ib[y * pn + x] * Cv + c]; return; }
+    const int64_t base = (int64_t)b * pn * pn;
+    auto rowid = [&](int64_t pos) -> int64_t { return FROM_H ? base + pos : idx[base + pos]; };
+    if (pn == P) { up[i] = codebook[rowid(y * pn + x) * Cv + c]; return; }
     const int32_t* iy = tap_idx + y * 4; const float* wy = tap_w + y * 4;
     const int32_t* ix = tap_idx + x * 4; const float* wx = tap_w + x * 4;
     float rr[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-        const int64_t* ir = ib + iy[a] * pn;
-        float acc = codebook[ir[ix[0]] * Cv + c] * wx[0];
-        acc = vm_fma(codebook[ir[ix[1]] * Cv + c], wx[1], acc);
-        acc = vm_fma(codebook[ir[ix[2]] * Cv + c], wx[2], acc);
-        acc = vm_fma(codebook[ir[ix[3]] * Cv + c], wx[3], acc);
+        const int64_t ro = (int64_t)iy[a] * pn;
+        float acc = codebook[rowid(ro + ix[0]) * Cv + c] * wx[0];
+        acc = vm_fma(codebook[rowid(ro + ix[1]) * Cv + c], wx[1], acc);
+        acc = vm_fma(codebook[rowid(ro + ix[2]) * Cv + c], wx[2], acc);
+        acc = vm_fma(codebook[rowid(ro + ix[3]) * Cv + c], wx[3], acc);
         rr[a] = acc;
     }
     float o = rr[0] * wy[0];
@@ -58,7 +61,19 @@ extern "C" int varhip_quant_accum_f32(const int64_t* idx, const float* codebook,
     const int64_t tot = (int64_t)B * P * P * Cv;
     VhScope sc(VH_FAM_OTHER, (hipStream_t)stream, 2.0 * tot * 9 * Cv, 16.0 * tot);
     const unsigned blocks = (unsigned)((tot + 255) / 256);
-    hipLaunchKernelGGL(k_gather_up, dim3(blocks), dim3(256), 0, (hipStream_t)stream, idx, codebook, tap_idx, tap_w, up, B, pn, P, Cv);
+    hipLaunchKernelGGL(k_gather_up<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, idx, codebook, tap_idx, tap_w, up, B, pn, P, Cv);
+    hipLaunchKernelGGL(k_phi_accum, dim3(blocks), dim3(256), 0, (hipStream_t)stream, up, phi_w, phi_b, ratio, 1.0f - ratio, f_hat, B, P, Cv);
+    return vh_launch_status();
+}
+
+extern "C" int varhip_quant_accum_h_f32(const float* h, const int32_t* tap_idx, const float* tap_w, const float* phi_w, const float* phi_b,
+                                        float ratio, float* up, float* f_hat, int B, int pn, int P, int Cv, varhip_stream_t stream) {
+    if (B <= 0 || pn <= 0 || P <= 0 || pn > P || Cv <= 0 || Cv > 64 || !h) return VARHIP_EINVAL;
+    if (pn != P && (!tap_idx || !tap_w)) return VARHIP_EINVAL;
+    const int64_t tot = (int64_t)B * P * P * Cv;
+    VhScope sc(VH_FAM_OTHER, (hipStream_t)stream, 2.0 * tot * 9 * Cv, 16.0 * tot);
+    const unsigned blocks = (unsigned)((tot + 255) / 256);
+    hipLaunchKernelGGL(k_gather_up<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const int64_t*)nullptr, h, tap_idx, tap_w, up, B, pn, P, Cv);
     hipLaunchKernelGGL(k_phi_accum, dim3(blocks), dim3(256), 0, (hipStream_t)stream, up, phi_w, phi_b, ratio, 1.0f - ratio, f_hat, B, P, Cv);
     return vh_launch_status();
 }

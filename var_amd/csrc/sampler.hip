@@ -152,3 +152,32 @@ extern "C" int varhip_cfg_sample_f32(const float* logits, const float* noise, in
                        (float)(1.0 + t_cfg), (float)t_cfg, top_k, top_p > 0.0 ? 1 : 0, (float)(1.0 - top_p));
     return vh_launch_status();
 }
+
+// ---- gumbel softmax of the more_smooth path (helpers.py:22-36, var.py:178-180): y = softmax((x*mul - ln(noise)) / tau) per row.
+// One 256-thread workgroup per row; the row sum is the canonical W256 sum, -ln is include/var_math.h's vm_log.
+__global__ void __launch_bounds__(256) k_gumbel_softmax(const float* __restrict__ x, const float* __restrict__ noise, float* __restrict__ y,
+                                                        int V, float mul, float tau) {
+    extern __shared__ __attribute__((aligned(16))) float zs[];
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    const int64_t row = blockIdx.x;
+    float m = -INFINITY;
+    for (int i = tid; i < V; i += 256) {
+        const float g = -vm_log(noise[row * V + i]);
+        const float z = (x[row * V + i] * mul + g) / tau;
+        zs[i] = z; m = fmaxf(m, z);
+    }
+    m = vh_block_max256(m, red);
+    float part = 0.f;
+    for (int i = tid; i < V; i += 256) { const float e = vm_exp(zs[i] - m); zs[i] = e; part = part + e; }
+    const float S = vh_block_sum256(part, red);
+    for (int i = tid; i < V; i += 256) y[row * V + i] = zs[i] / S;
+}
+
+extern "C" int varhip_gumbel_softmax_f32(const float* x, const float* noise, float* y, int64_t rows, int V, float mul, float tau, varhip_stream_t stream) {
+    if (rows < 0 || V <= 0 || (V & 255) || V > 16384) return VARHIP_EINVAL;
+    if (rows == 0) return 0;
+    VhScope sc(VH_FAM_SAMPLER, (hipStream_t)stream, 0, 12.0 * rows * V);
+    hipLaunchKernelGGL(k_gumbel_softmax, dim3((unsigned)rows), dim3(256), sizeof(float) * V, (hipStream_t)stream, x, noise, y, V, mul, tau);
+    return vh_launch_status();
+}

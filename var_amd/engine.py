@@ -206,6 +206,7 @@ class SamplingEngine:
             blocks.append(d)
         w['blocks'] = blocks
         w['codebook'] = g(quant.embedding.weight, 'codebook')
+        w['codebook_T'] = w['codebook'].t().contiguous()          # [Cvae][V]: "probabilities @ codebook" as an NT GEMM (more_smooth)
         phis = list(quant.quant_resi.phis())
         w['phi'] = [(g(p.weight, 'phi').permute(0, 2, 3, 1).contiguous(), g(p.bias, 'phi'), float(p.resi_ratio)) for p in phis]
         w['taps'] = {}
@@ -246,7 +247,8 @@ class SamplingEngine:
     @torch.no_grad()
     def sample(self, B: int, label_B: torch.Tensor, rng: Optional[torch.Generator], cfg: float, top_k: int, top_p: float,
                noises=None, force_idx: Optional[torch.Tensor] = None, trace: bool = False,
-               decode: bool = True, gt_tokens: Optional[torch.Tensor] = None, keep_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+               decode: bool = True, gt_tokens: Optional[torch.Tensor] = None, keep_mask: Optional[torch.Tensor] = None,
+               more_smooth: bool = False, gumbel_noises=None) -> torch.Tensor:
         """label_B: int64 [B] on the device.  noises: optional per-scale Exp(1) tensors [B*l, V] — a list, or a callable
         (si, l) -> tensor (tests inject the CPU generator's stream; var_amd.multi hands each rank its rows); by default they
         are drawn with `exponential_(generator=rng)` exactly as torch.multinomial (helpers.py:19) would.
@@ -265,8 +267,17 @@ class SamplingEngine:
             raise ValueError(f'labels must lie in [0, {var.num_classes}]')
         label_B = label_B.to(dev).contiguous()
         tr = dict(logits=[], idx=[], f_hat=[], pooled=[]) if trace else None
-        gt = keep_u8 = skip = None
+        gt = keep_u8 = skip = masked = None
         draws = 0
+        if more_smooth:
+            if gt_tokens is not None:
+                raise NotImplementedError('inpainting with more_smooth: the reference reads logits it did not compute on fully kept scales')
+            lmax = max(p * p for p in var.patch_nums)
+            if 'probs' not in ws:
+                ws['masked'] = torch.empty(B * lmax, V, dtype=torch.float32, device=dev)
+                ws['probs'] = torch.empty(B * lmax, V, dtype=torch.float32, device=dev)
+                ws['h'] = torch.empty(B * lmax, Cv, dtype=torch.float32, device=dev)
+            masked = ws['masked']
         if gt_tokens is not None:
             if keep_mask is None or tuple(keep_mask.shape) != tuple(gt_tokens.shape) or tuple(gt_tokens.shape) != (B, var.L):
                 raise ValueError('Mask shape must match the latent token shape obtained from vae.img_to_idxBl')
@@ -328,7 +339,7 @@ class SamplingEngine:
                     noise = torch.empty(B * l, V, dtype=torch.float32, device=dev).exponential_(1, generator=rng)
                 t = cfg * (si / var.num_stages_minus_1) if var.num_stages_minus_1 > 0 else 0.0
                 idx = ws['idx'][:B * l]
-                hip.call('cfg_sample_f32', ws['logits'], noise, idx, None, B, l, V, float(t), int(top_k), float(top_p))
+                hip.call('cfg_sample_f32', ws['logits'], noise, idx, masked, B, l, V, float(t), int(top_k), float(top_p))
                 if gt is not None:                                        # torch.where(mask, gt_tokens, sampled) (var.py:326-328)
                     hip.call('token_select_i64', keep_u8[:, cur - l:cur].contiguous(), gt[:, cur - l:cur].contiguous(), idx, idx, B * l)
                 if trace: tr['idx'].append(idx.view(B, l).clone())
@@ -337,7 +348,19 @@ class SamplingEngine:
             # quantizer step (var.py:177-183)
             ti, tw = w['taps'].get(pn, (None, None))
             pw, pb, ratio = w['phi'][phi_index(si, S, len(w['phi']))]
-            hip.call('quant_accum_f32', idx, w['codebook'], ti, tw, pw, pb, ratio, ws['up'], ws['f_hat'], B, pn, P, Cv)
+            if more_smooth:
+                # h = gumbel_softmax(filtered logits * (1+ratio), tau) @ codebook, a second Exp(1) fill per scale (var.py:178-180)
+                r_ = si / var.num_stages_minus_1 if var.num_stages_minus_1 > 0 else 0.0
+                gum_t = max(0.27 * (1 - r_ * 0.95), 0.005)
+                if gumbel_noises is not None:
+                    gn = gumbel_noises[si].to(dev, torch.float32).contiguous()
+                else:
+                    gn = torch.empty(B * l, V, dtype=torch.float32, device=dev).exponential_(generator=rng)
+                hip.call('gumbel_softmax_f32', masked, gn, ws['probs'], B * l, V, float(1 + r_), float(gum_t))
+                self.gemm(ws['probs'], w['codebook_T'], None, ws['h'], B * l)
+                hip.call('quant_accum_h_f32', ws['h'], ti, tw, pw, pb, ratio, ws['up'], ws['f_hat'], B, pn, P, Cv)
+            else:
+                hip.call('quant_accum_f32', idx, w['codebook'], ti, tw, pw, pb, ratio, ws['up'], ws['f_hat'], B, pn, P, Cv)
             if trace: tr['f_hat'].append(ws['f_hat'].permute(0, 3, 1, 2).clone())
             if si != S - 1:
                 pq = var.patch_nums[si + 1]

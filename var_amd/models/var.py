@@ -87,8 +87,6 @@ class VAR(nn.Module):
                                  top_k=0, top_p=0.0, more_smooth=False) -> torch.Tensor:
         """Sample B images; returns (B, 3, H, W) in [0, 1].  Same arguments and RNG consumption as the reference
         (var.py:126-190): `g_seed` seeds self.rng, one Exp(1) fill of shape (B*l, V) is drawn per scale."""
-        if more_smooth:
-            raise NotImplementedError('more_smooth (gumbel) sampling is a "next" row of SURVEY.md §8(f); FID/IS sampling uses more_smooth=False')
         dev = self.lvl_1L.device
         if dev.type != 'cuda':
             raise RuntimeError('VAR.autoregressive_infer_cfg: this build runs the sampling loop on MI355X HIP kernels only; move the model to a '
@@ -99,7 +97,7 @@ class VAR(nn.Module):
             label_B = torch.multinomial(self.uniform_prob, num_samples=B, replacement=True, generator=rng).reshape(B)
         elif isinstance(label_B, int):
             label_B = torch.full((B,), fill_value=self.num_classes if label_B < 0 else label_B, device=dev)
-        return self.engine().sample(B, label_B.to(dev).long(), rng, cfg, top_k, top_p)
+        return self.engine().sample(B, label_B.to(dev).long(), rng, cfg, top_k, top_p, more_smooth=bool(more_smooth))
 
     # ---- teacher-forced forward (PyTorch; reference var.py:118-124,192-234) ---------------------------------------------
     def get_logits(self, h_or_h_and_residual, cond_BD: Optional[torch.Tensor]):
