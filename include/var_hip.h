@@ -140,6 +140,15 @@ int varhip_first_map_f32(const float* class_emb, const int64_t* labels, int num_
 int varhip_conv3x3_nhwc_f32(const float* in, const float* w, const float* bias, const float* resid, float* out,
                             int B, int H, int W, int Cin, int Cout, int up2, int out_mode, varhip_stream_t stream);
 
+/* Upsample2x (basic_vae.py:27-28: nearest 2x, then conv3x3) as four 2x2 convolutions on the LOW-resolution map, one per output
+ * parity (py,px): the 3x3 taps that read the same source pixel through the upsampling are pre-summed, 2.25x fewer MACs.
+ *   varhip_upconv_pack_f32 : w [Cout][3][3][Cin] -> w_phase [4][Cout][2][2][Cin]   (one-time, per weight)
+ *   varhip_upconv_phase_f32: in [B][H/2][W/2][Cin] -> out [B][H][W][Cout], bias added
+ * Mathematically equal to varhip_conv3x3_nhwc_f32(up2=1); rounding differs at the 1e-7 level (decoder only: pixels, not tokens). */
+int varhip_upconv_pack_f32(const float* w, float* w_phase, int Cin, int Cout, varhip_stream_t stream);
+int varhip_upconv_phase_f32(const float* in, const float* w_phase, const float* bias, float* out,
+                            int B, int H, int W, int Cin, int Cout, varhip_stream_t stream);
+
 /* GroupNorm statistics: stats[b][g] = {mean, rstd} over (HW, C/G) with biased variance (basic_vae.py:18-19, eps 1e-6).
  * scratch: caller-provided, at least varhip_gn_scratch_elems(B,HW,C,G) doubles. */
 int64_t varhip_gn_scratch_elems(int B, int HW, int C, int G);

@@ -500,6 +500,49 @@ int varref_conv3x3_nhwc_f32(const float* in, const float* w, const float* bias, 
     return 0;
 }
 
+/* Upsample2x (basic_vae.py:27-28) as four 2x2 convolutions on the low-resolution map: taps of the 3x3 kernel that read the same
+ * source pixel through the nearest-neighbour upsampling are pre-summed.  w_phase: [4][Cout][2][2][Cin], phase = 2*py + px. */
+int varref_upconv_pack_f32(const float* w, float* wp, int Cin, int Cout) {
+    for (int ph = 0; ph < 4; ++ph)
+        for (int co = 0; co < Cout; ++co)
+            for (int a = 0; a < 2; ++a)
+                for (int b = 0; b < 2; ++b)
+                    for (int ci = 0; ci < Cin; ++ci) {
+                        int py = ph >> 1, px = ph & 1;
+                        int ky0 = py == 0 ? (a == 0 ? 0 : 1) : (a == 0 ? 0 : 2), ky1 = py == 0 ? (a == 0 ? 0 : 2) : (a == 0 ? 1 : 2);
+                        int kx0 = px == 0 ? (b == 0 ? 0 : 1) : (b == 0 ? 0 : 2), kx1 = px == 0 ? (b == 0 ? 0 : 2) : (b == 0 ? 1 : 2);
+                        float s = 0.0f;
+                        for (int ky = ky0; ky <= ky1; ++ky)
+                            for (int kx = kx0; kx <= kx1; ++kx) s = s + w[(((int64_t)co * 3 + ky) * 3 + kx) * Cin + ci];
+                        wp[((((int64_t)ph * Cout + co) * 2 + a) * 2 + b) * Cin + ci] = s;
+                    }
+    return 0;
+}
+int varref_upconv_phase_f32(const float* in, const float* wp, const float* bias, float* out, int B, int H, int W, int Cin, int Cout) {
+    if ((H & 1) || (W & 1)) return VARHIP_EINVAL;
+    const int Hl = H / 2, Wl = W / 2;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int Y = 0; Y < H; ++Y)
+            for (int X = 0; X < W; ++X) {
+                const int y = Y >> 1, py = Y & 1, x = X >> 1, px = X & 1, ph = 2 * py + px;
+                for (int co = 0; co < Cout; ++co) {
+                    float acc = 0.0f;
+                    for (int a = 0; a < 2; ++a) {
+                        int yy = y + a - 1 + py; if (yy < 0 || yy >= Hl) continue;
+                        for (int bb = 0; bb < 2; ++bb) {
+                            int xx = x + bb - 1 + px; if (xx < 0 || xx >= Wl) continue;
+                            const float* ip = in + (((int64_t)b * Hl + yy) * Wl + xx) * Cin;
+                            const float* w = wp + ((((int64_t)ph * Cout + co) * 2 + a) * 2 + bb) * Cin;
+                            for (int ci = 0; ci < Cin; ++ci) acc = vm_fma(ip[ci], w[ci], acc);
+                        }
+                    }
+                    out[(((int64_t)b * H + Y) * W + X) * Cout + co] = acc + bias[co];
+                }
+            }
+    return 0;
+}
+
 int64_t varref_gn_scratch_elems(int B, int HW, int C, int G) { (void)HW; (void)C; return (int64_t)B * G * 2; }
 
 /* GroupNorm(32, C, eps=1e-6) statistics (basic_vae.py:18-19): biased variance over (HW, C/G); two-pass in double */

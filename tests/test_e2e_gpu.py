@@ -136,7 +136,7 @@ def test_public_api_and_properties():
     with pytest.raises(ValueError):
         eng.sample(2, torch.tensor([5, 1001], device='cuda'), None, 1.5, 0, 0.0)
     with pytest.raises(NotImplementedError):
-        var.autoregressive_infer_cfg(2, 1, g_seed=0, more_smooth=True)
+        var.smooth_sampling()
 
 
 def test_incremental_fhat_equals_embed_to_fhat_and_decoder_api():

@@ -252,6 +252,20 @@ def test_conv3x3_exact(B, H, W, Cin, Cout, up2, resid, mode):
     check(f'conv3x3 {Cin}->{Cout} {H}x{W} up{up2} mode{mode}', g, wv)
 
 
+@pytest.mark.parametrize('B,H,W,Cin,Cout', [(2, 6, 6, 32, 32), (1, 32, 32, 640, 640), (2, 64, 48, 160, 160), (1, 16, 16, 64, 128)])
+def test_upconv_phase(B, H, W, Cin, Cout):
+    """Upsample2x as four 2x2 phase convs: bit-exact vs its CPU twin, and equal to the plain nearest-2x + 3x3 conv up to the
+    rounding of the pre-summed weights (tolerance; the decoder is off the token path)"""
+    rng = np.random.default_rng(H + W + Cin)
+    x = rnd(rng, B, H // 2, W // 2, Cin); w = rnd(rng, Cout, 3, 3, Cin, scale=(1.0 / (9 * Cin)) ** 0.5); bias = rnd(rng, Cout, scale=0.1)
+    wp = np.zeros((4, Cout, 2, 2, Cin), np.float32)
+    (gp,), (rp,) = both('upconv_pack_f32', [w, wp, Cin, Cout], [1]); check('upconv pack', gp, rp)
+    out = np.zeros((B, H, W, Cout), np.float32)
+    (g,), (r,) = both('upconv_phase_f32', [x, rp, bias, out, B, H, W, Cin, Cout], [3]); check('upconv phase vs twin', g, r)
+    (g9,), (r9,) = both('conv3x3_nhwc_f32', [x, w, bias, None, np.zeros_like(out), B, H, W, Cin, Cout, 1, 0], [4])
+    check('upconv phase vs 9-tap definition', g, r9, exact=False, atol=5e-5, rtol=1e-5)      # 1.9e-5 measured at K = 9*640, |out| <= 4.6
+
+
 @pytest.mark.parametrize('B,HW,C', [(2, 9, 32), (2, 256, 640), (1, 4096, 320), (2, 2304, 160), (3, 100, 64)])
 def test_groupnorm(B, HW, C):
     _, hip = _setup()

@@ -53,6 +53,53 @@ __global__ void __launch_bounds__(256, MINW) k(const float* __restrict__ A, cons
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     const int nk = K / BK;
+    if (FLAGS & 16) {           // ---- 2-deep register prefetch: tile kt+2 is in flight while tile kt is computed ----
+        f32x4 ra2[NA][2], rb2[NB][2];
+        auto load_tile2 = [&](int kt) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) { const float* s = a_ptr[i] + kt * BK; ra2[i][0] = *(const f32x4*)s; ra2[i][1] = *(const f32x4*)(s + 4); }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) { const float* s = b_ptr[i] + kt * BK; rb2[i][0] = *(const f32x4*)s; rb2[i][1] = *(const f32x4*)(s + 4); }
+        };
+        auto store_tile2 = [&](int st) {
+            float* sA = smem + st * STAGE; float* sB = sA + BM * LDSW;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) { float* d = sA + a_off[i]; f32x4 ev = {ra2[i][0][0], ra2[i][0][2], ra2[i][1][0], ra2[i][1][2]}, od = {ra2[i][0][1], ra2[i][0][3], ra2[i][1][1], ra2[i][1][3]}; *(f32x4*)d = ev; *(f32x4*)(d + 4) = od; }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) { float* d = sB + b_off[i]; f32x4 ev = {rb2[i][0][0], rb2[i][0][2], rb2[i][1][0], rb2[i][1][2]}, od = {rb2[i][0][1], rb2[i][0][3], rb2[i][1][1], rb2[i][1][3]}; *(f32x4*)d = ev; *(f32x4*)(d + 4) = od; }
+        };
+        auto compute = [&](int cur, auto&& mid) {
+            const float* sA = smem + cur * STAGE + (wm * TM * 32 + r) * LDSW + h * 4;
+            const float* sB = smem + cur * STAGE + BM * LDSW + (wn * TN * 32 + r) * LDSW + h * 4;
+#pragma unroll
+            for (int c = 0; c < CPR; ++c) {
+                if (c == (CPR + 1) / 2) mid();
+                f32x4 af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = *(const f32x4*)(sA + i * 32 * LDSW + c * 8);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = *(const f32x4*)(sB + j * 32 * LDSW + c * 8);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+            }
+        };
+        // prologue: tile 0 -> LDS stage 0; tile 1 -> regs set 1 (ra); tile 2 -> regs set 2 (ra2)
+        load_tile(0); store_tile(0); __syncthreads();
+        load_tile(1); if (nk > 2) load_tile2(2);
+        for (int kt = 0; kt < nk; kt += 2) {
+            // even tile kt (stage 0): mid-tile, write tile kt+1 (regs set 1) into stage 1, then refill set 1 with tile kt+3
+            compute(0, [&] { if (kt + 1 < nk) { store_tile(1); if (kt + 3 < nk) load_tile(kt + 3); } });
+            __syncthreads();
+            if (kt + 1 >= nk) break;
+            // odd tile kt+1 (stage 1): mid-tile, write tile kt+2 (regs set 2) into stage 0, then refill set 2 with tile kt+4
+            compute(1, [&] { if (kt + 2 < nk) { store_tile2(0); if (kt + 4 < nk) load_tile2(kt + 4); } });
+            __syncthreads();
+        }
+    } else {
     load_tile(0); store_tile(0); store_tile(1); __syncthreads();
     f32x4 af[TM], bf[TN];
 #pragma unroll
@@ -81,6 +128,7 @@ __global__ void __launch_bounds__(256, MINW) k(const float* __restrict__ A, cons
                     for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
         }
         if (!(FLAGS & 4)) __syncthreads();
+    }
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -220,6 +268,9 @@ int main(int argc, char** argv) {
     run<2, 2, 2, 2, 32, 0, 1>("baseline 128x128 BK32", A, W, out, M, N, K);
     float* ref; hipMalloc(&ref, (size_t)M * N * 4);
     run<2, 2, 2, 2, 32, 0, 1>("baseline again (reference output)", A, W, ref, M, N, K);
+    run<2, 2, 2, 2, 32, 16, 1>("reg-staged, 2-deep prefetch BK32", A, W, out, M, N, K);
+    { std::vector<float> a(4096), b(4096); hipMemcpy(a.data(), out, 16384, hipMemcpyDeviceToHost); hipMemcpy(b.data(), ref, 16384, hipMemcpyDeviceToHost); int bad = 0; for (int i = 0; i < 4096; ++i) bad += a[i] != b[i]; printf("   2-deep mismatches %d\n", bad); }
+    run<2, 2, 2, 2, 16, 16, 1>("reg-staged, 2-deep prefetch BK16", A, W, out, M, N, K);
     run_dma<64, 2, 32, 1>("DMA 128x128 BK32 2 stages", A, W, out, M, N, K, ref);
     run_dma<64, 2, 16, 1>("DMA 128x128 BK16 2 stages", A, W, out, M, N, K, ref);
     run_dma<64, 2, 16, 4>("DMA 128x128 BK16 2 stages minw4", A, W, out, M, N, K, ref);

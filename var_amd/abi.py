@@ -33,6 +33,8 @@ SIGNATURES = {
     'nhwc_to_nchw_f32':  [P, P, I, I, I],
     'nearest_code_f32':  [P, P, P, I, I, I],
     'token_select_i64':  [P, P, P, P, L],
+    'upconv_pack_f32':   [P, P, I, I],
+    'upconv_phase_f32':  [P, P, P, P, I, I, I, I, I],
     'quant_accum_h_f32': [P, P, P, P, P, F, P, P, I, I, I, I],
     'gumbel_softmax_f32': [P, P, P, L, I, F, F],
 }

@@ -82,6 +82,11 @@ class DecoderEngine:
                 w[k] = v.reshape(v.shape[0], v.shape[1])            # 1x1 conv == linear
             else:
                 w[k] = v
+        for k in [k for k in w if k.endswith('.upsample.conv.weight')]:        # Upsample2x convs: pre-summed 2x2 phase weights
+            cout, _, _, cin = w[k].shape
+            wp = torch.empty(4, cout, 2, 2, cin, dtype=torch.float32, device=w[k].device)
+            hip.call('upconv_pack_f32', w[k], wp, cin, cout)
+            w[k[:-len('weight')] + 'phase'] = wp
         self.w = w
         self.nlev = 1 + max(int(k.split('.')[2]) for k in w if k.startswith('decoder.up.'))
         self._sig = sig
@@ -153,9 +158,13 @@ class DecoderEngine:
                 h = self.resblock(h, f'decoder.up.{lev}.block.{ib}', B, Hh, Ww)
                 if f'decoder.up.{lev}.attn.{ib}.norm.weight' in self.w:
                     h = self.attnblock(h, f'decoder.up.{lev}.attn.{ib}', B, Hh, Ww)
-            if lev != 0:
+            if lev != 0:                                             # Upsample2x: nearest 2x + conv3x3, as 4 phase convs on the low-res map
                 Hh, Ww = 2 * Hh, 2 * Ww
-                h = self.conv3(h, f'decoder.up.{lev}.upsample.conv', B, Hh, Ww, up2=1)
+                key = f'decoder.up.{lev}.upsample.conv'
+                wp = self.w[key + '.phase']
+                up = torch.empty((B, Hh, Ww, wp.shape[1]), dtype=torch.float32, device=h.device)
+                hip.call('upconv_phase_f32', h, wp, self.w[key + '.bias'], up, B, Hh, Ww, wp.shape[4], wp.shape[1])
+                h = up
         h = self.gn(h, 'decoder.norm_out', B, Hh * Ww, True)
         return self.conv3(h, 'decoder.conv_out', B, Hh, Ww, out_mode=1 if denorm else 2)
 
