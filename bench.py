@@ -87,19 +87,29 @@ def main():
     if rank == 0:
         ips = B_total * args.steps / dt
         flops_img = var.engine().flops_per_image()
-        dec_flops_img = tt['conv3x3']['flops'] / max(args.steps * B_local, 1)
+        dec_flops_img = var.engine().dec.flops_per_image_reference(pns[-1])          # as the reference computes the decoder (9-tap upsample convs)
         fam = max(('gemm', 'conv3x3', 'attn'), key=lambda k: tt[k]['ms'])
         f = tt[fam]
         achieved = f['flops'] / (f['ms'] * 1e-3) / 1e12 if f['ms'] > 0 else 0.0
+        kname = {'gemm': 'k_mfma_gemm<2,2,2,2,32,false,true>', 'conv3x3': 'k_mfma_gemm<1,5,4,1,16,true,true>', 'attn': 'k_attn_cached'}[fam]
+        traffic = None                                                       # HBM-side bytes per launch from a separate rocprofv3 --pmc pass
+        try:
+            pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))['kernels'].get(kname)
+            if pm and args.batch == 64 and args.depth == 16: traffic = pm['traffic_bytes_per_launch']
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             'metric': '256x256 images/sec (CFG=1.5) VAR-d%d' % args.depth, 'value': round(ips, 3), 'unit': 'images/sec', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'VAR-d{args.depth} 256x256 full 10-scale pyramid, CFG=1.5, top_k=900, top_p=0.96, batch={B_local}/GPU, random-init (detinit seed 0)',
                        'global_batch': B_total, 'parallelism': f'dp{world} (batch shard, RCCL all-gather of decoded images)', 'rng_mode': args.rng_mode},
-            'roofline': {'bound': 'mfma', 'kernel': {'gemm': 'k_mfma_gemm<..,false> (GEMM)', 'conv3x3': 'k_mfma_gemm<..,true> (3x3 conv)', 'attn': 'k_attn_cached'}[fam],
+            'roofline': {'bound': 'mfma', 'kernel': kname,
                          'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                         'traffic': None, 'launches': f['launches'], 'avg_launch_ms': round(f['ms'] / max(f['launches'], 1), 5)},
+                         'traffic': traffic, 'traffic_source': 'profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)' if traffic else None,
+                         'launches': f['launches'], 'avg_launch_ms': round(f['ms'] / max(f['launches'], 1), 5),
+                         'algorithmic_gflop_per_launch': round(f['flops'] / max(f['launches'], 1) / 1e9, 3),
+                         'algorithmic_mbytes_per_launch': round(f['bytes'] / max(f['launches'], 1) / 1e6, 3)},
             'kernel_time_ms_per_step': {k: round(v['ms'] / args.steps, 3) for k, v in tt.items()},
             'kernel_tflops': {k: round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2) for k, v in tt.items() if v['ms'] > 0 and v['flops'] > 0},
             'whole_path': {'gflop_per_image': round((flops_img + dec_flops_img) / 1e9, 1),

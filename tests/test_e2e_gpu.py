@@ -223,6 +223,35 @@ def test_more_smooth_vs_oracle_and_reference(golden_dir):
     assert torch.equal(a, b) and not torch.equal(a, c) and torch.isfinite(a).all()
 
 
+@pytest.mark.parametrize('width,heads,saln,pns', [(1920, 30, False, (1, 2, 3)), (2304, 36, True, (1, 2, 3, 4, 6))])
+def test_wide_models_vs_oracle(width, heads, saln, pns):
+    """the widths of VAR-d30 (C=1920, 30 heads; BASELINE.json configs[3]) and VAR-d36 (C=2304, 36 heads, shared AdaLN, the 512px
+    scale schedule's first scales; configs[4]) at depth 2: every C-dependent kernel (LayerNorm with C % 256 != 0, GEMM N = 1920 /
+    5760 / 7680, 30-36 heads in attention and q/k/v prep) bit-exact against the oracle, free-running"""
+    from models import VAR, VQVAE
+    from var_amd import shapes
+    from var_amd.detinit import fill_module_, make_state_dict
+    depth, ch, labels, seed = 2, 32, [11, 987], 5
+    with contextlib.redirect_stdout(io.StringIO()):
+        vae = VQVAE(vocab_size=4096, z_channels=32, ch=ch, test_mode=True, share_quant_resi=4, v_patch_nums=pns).cuda()
+        var = VAR(vae_local=vae, depth=depth, embed_dim=width, num_heads=heads, shared_aln=saln, attn_l2_norm=True, patch_nums=pns).cuda().eval()
+    fill_module_(var, depth, 0, 'var.'); fill_module_(vae, depth, 0, 'vae.')
+    g = torch.Generator().manual_seed(seed)
+    noise = [torch.empty(len(labels) * pn * pn, 4096).exponential_(1, generator=g) for pn in pns]
+    img = var.engine().sample(len(labels), torch.tensor(labels, device='cuda'), None, 1.5, 900, 0.96, noises=noise, trace=True)
+    tr = var.engine().last_trace
+    util.ensure_oracle_built()
+    from oracle.var_oracle import OracleVAR
+    var_sd = make_state_dict(shapes.var_shapes(depth, pns, shared_aln=saln, embed_dim=width, num_heads=heads), depth=depth, seed=0, prefix='var.')
+    var_sd['lvl_1L'] = np.concatenate([np.full((p * p,), i, dtype=np.int64) for i, p in enumerate(pns)]).reshape(1, -1)
+    vae_sd = make_state_dict(shapes.vae_shapes(ch=ch, patch_nums=pns, include_encoder=False), depth=depth, seed=0, prefix='vae.')
+    r = OracleVAR(var_sd, vae_sd, pns, depth, shared_aln=saln).run(labels, [n.numpy() for n in noise], 1.5, 900, 0.96)
+    ok, m = util.diff_report(f'C={width} tokens vs oracle', torch.cat(tr['idx'], 1).cpu().numpy(), r['idx']); print(m); assert ok, m
+    for si in range(len(pns)):
+        ok, m = util.diff_report(f'C={width} logits s{si} vs oracle (exact)', tr['logits'][si].cpu().numpy(), r['logits'][si]); print(m); assert ok, m
+    ok, m = util.diff_report(f'C={width} image vs oracle', img.cpu().numpy(), r['img'], atol=1e-5); print(m); assert ok, m
+
+
 def test_d16_batch64_properties():
     """BASELINE.json configs[1] at full size (d16, 10 scales, B=64): determinism and agreement of the first two images with the
     B=2 reference fixture when fed the same noise rows (batch-slice invariance at the headline shape)."""

@@ -142,6 +142,24 @@ class DecoderEngine:
         hip.call('gemm_nt_f32', p, HW, vt, HW, None, o, Cc, HW, Cc, HW, EPI_NONE, None, 0, None, 0, 1, 0, B, HW * HW, Cc * HW, HW * Cc)
         return self.lin(o, pre + '.proj_out', resid=x.view(B * HW, Cc)).view(B, Hh, Ww, Cc)
 
+    def flops_per_image_reference(self, P: int) -> float:
+        """FLOPs (2/MAC) of one decode as the REFERENCE computes it (9-tap upsample convs; SURVEY.md §8d: 393.7 G at P=16, ch=160)"""
+        self.refresh()
+        w = self.w
+        def c3(key, hw): co, _, _, ci = w[key + '.weight'].shape; return 2.0 * hw * co * 9 * ci
+        def c1(key, hw): co, ci = w[key + '.weight'].shape; return 2.0 * hw * co * ci
+        def res(pre, hw): return c3(pre + '.conv1', hw) + c3(pre + '.conv2', hw) + (c1(pre + '.nin_shortcut', hw) if (pre + '.nin_shortcut.weight') in w else 0.0)
+        def att(pre, hw): c = w[pre + '.proj_out.weight'].shape[0]; return c1(pre + '.qkv', hw) + c1(pre + '.proj_out', hw) + 2.0 * 2 * hw * hw * c
+        hw = P * P
+        f = c3('post_quant_conv', hw) + c3('decoder.conv_in', hw) + res('decoder.mid.block_1', hw) + att('decoder.mid.attn_1', hw) + res('decoder.mid.block_2', hw)
+        for lev in reversed(range(self.nlev)):
+            for ib in range(3):
+                f += res(f'decoder.up.{lev}.block.{ib}', hw)
+                if f'decoder.up.{lev}.attn.{ib}.norm.weight' in w: f += att(f'decoder.up.{lev}.attn.{ib}', hw)
+            if lev != 0:
+                hw *= 4; f += c3(f'decoder.up.{lev}.upsample.conv', hw)
+        return f + c3('decoder.conv_out', hw)
+
     def decode_nhwc(self, f_hat: torch.Tensor, denorm: bool = True) -> torch.Tensor:
         """[B,P,P,Cvae] channels-last -> [B,3,16P,16P]; denorm=True: in [0,1] (clamp and (x+1)/2 fused into the last conv, what
         autoregressive_infer_cfg returns); denorm=False: clamped to [-1,1] (VQVAE.fhat_to_img's contract)"""
