@@ -164,6 +164,22 @@ int varhip_softmax_rows_f32(const float* x, float* out, int64_t rows, int n, flo
 int varhip_nchw_to_nhwc_f32(const float* in, float* out, int B, int C, int HW, varhip_stream_t stream);
 int varhip_nhwc_to_nchw_f32(const float* in, float* out, int B, int C, int HW, varhip_stream_t stream);
 
+/* ---- encode side and teacher forcing ("next" rows of SURVEY.md §8f: image -> tokens -> teacher-forced logits) -----------------
+ * Downsample2x of the encoder (basic_vae.py:31-37): F.pad(x,(0,1,0,1)) + Conv2d(k=3, stride=2): in [B][2H][2W][Cin] -> out [B][H][W][Cout] */
+int varhip_conv3x3_s2_nhwc_f32(const float* in, const float* w, const float* bias, float* out,
+                               int B, int H, int W, int Cin, int Cout, varhip_stream_t stream);
+/* image [B][C][HW] -> [B][HW][Cpad] with zero channels C..Cpad-1 (conv kernels need Cin % 16 == 0; zero channels add exact zeros) */
+int varhip_nchw_to_nhwc_pad_f32(const float* in, float* out, int B, int C, int HW, int Cpad, varhip_stream_t stream);
+/* pooled[b][t][:] = mean of f[b] over the adaptive window of output cell t   (F.interpolate(mode='area'), quant.py:150,183) */
+int varhip_area_pool_f32(const float* f, float* pooled, int B, int P, int pq, int Cv, varhip_stream_t stream);
+/* x[b][t][:] = x[b+B][t][:] = word_w . pooled[b][t][:] + word_b + lvl_pos[t][:]   (var.py:186-187, 206-207); x_out holds 2*B*lq rows */
+int varhip_word_embed_f32(const float* pooled, const float* word_w, const float* word_b, const float* lvl_pos,
+                          float* x_out, int B, int lq, int C, int Cv, varhip_stream_t stream);
+/* one scale of VectorQuantizer2.f_to_idxBl_or_fhat (quant.py:159-163): as varhip_quant_accum_f32, and f_rest -= the same h */
+int varhip_quant_residual_f32(const int64_t* idx, const float* codebook, const int32_t* tap_idx, const float* tap_w,
+                              const float* phi_w, const float* phi_b, float ratio, float* up, float* f_hat, float* f_rest,
+                              int B, int pn, int P, int Cv, varhip_stream_t stream);
+
 /* out[i] = keep[i] ? gt[i] : sampled[i]   — VAR.inpainting's torch.where(mask, gt_tokens, sampled_tokens) (var.py:312-328, fork) */
 int varhip_token_select_i64(const uint8_t* keep, const int64_t* gt, const int64_t* sampled, int64_t* out, int64_t n, varhip_stream_t stream);
 

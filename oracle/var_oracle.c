@@ -306,9 +306,9 @@ int varref_cfg_sample_f32(const float* logits, const float* noise, int64_t* idx_
 }
 
 /* codebook gather + bicubic up + Phi + f_hat accumulate  (var.py:177,182; quant.py:187-196, 199-206) */
-int varref_quant_accum_f32(const int64_t* idx, const float* codebook, const int32_t* tap_idx, const float* tap_w,
+static int quant_step_core(const int64_t* idx, const float* codebook, const int32_t* tap_idx, const float* tap_w,
                            const float* phi_w, const float* phi_b, float ratio,
-                           float* up, float* f_hat, int B, int pn, int P, int Cv) {
+                           float* up, float* f_hat, float* f_rest, int B, int pn, int P, int Cv) {
     if ((pn != P) && (!tap_idx || !tap_w)) return VARHIP_EINVAL;
     const float keep = 1.0f - ratio;
 #pragma omp parallel for collapse(2) schedule(static)
@@ -358,7 +358,51 @@ int varref_quant_accum_f32(const int64_t* idx, const float* codebook, const int3
                     float conv = acc + phi_b[co];
                     float hmix = u0[co] * keep + conv * ratio;       /* Phi.forward: h*(1-r) + conv(h)*r  (quant.py:205-206) */
                     f[co] = f[co] + hmix;                            /* f_hat.add_(h)  (quant.py:191,195) */
+                    if (f_rest) { float* fr = f_rest + (((int64_t)b * P + y) * P + x) * Cv; fr[co] = fr[co] - hmix; }   /* f_rest.sub_(h) (quant.py:163) */
                 }
+            }
+    return 0;
+}
+int varref_quant_accum_f32(const int64_t* idx, const float* codebook, const int32_t* tap_idx, const float* tap_w,
+                           const float* phi_w, const float* phi_b, float ratio,
+                           float* up, float* f_hat, int B, int pn, int P, int Cv) {
+    return quant_step_core(idx, codebook, tap_idx, tap_w, phi_w, phi_b, ratio, up, f_hat, NULL, B, pn, P, Cv);
+}
+/* one scale of the residual quantisation of an encoder feature map (quant.py:159-163): f_hat += h, f_rest -= h */
+int varref_quant_residual_f32(const int64_t* idx, const float* codebook, const int32_t* tap_idx, const float* tap_w,
+                              const float* phi_w, const float* phi_b, float ratio, float* up, float* f_hat, float* f_rest,
+                              int B, int pn, int P, int Cv) {
+    if (!f_rest) return VARHIP_EINVAL;
+    return quant_step_core(idx, codebook, tap_idx, tap_w, phi_w, phi_b, ratio, up, f_hat, f_rest, B, pn, P, Cv);
+}
+/* F.interpolate(f, (pq,pq), mode='area') == adaptive_avg_pool2d (quant.py:150,183), channels-last -> [B][pq*pq][Cv] */
+int varref_area_pool_f32(const float* f, float* pooled, int B, int P, int pq, int Cv) {
+    if (pq <= 0 || pq > P) return VARHIP_EINVAL;
+    for (int b = 0; b < B; ++b)
+        for (int t = 0; t < pq * pq; ++t) {
+            int oy = t / pq, ox = t % pq;
+            int y0 = (oy * P) / pq, y1 = ((oy + 1) * P + pq - 1) / pq, x0 = (ox * P) / pq, x1 = ((ox + 1) * P + pq - 1) / pq;
+            for (int c = 0; c < Cv; ++c) {
+                float s = 0.0f;
+                for (int y = y0; y < y1; ++y)
+                    for (int x = x0; x < x1; ++x) s = s + f[(((int64_t)b * P + y) * P + x) * Cv + c];
+                pooled[((int64_t)b * pq * pq + t) * Cv + c] = (s / (float)(y1 - y0)) / (float)(x1 - x0);
+            }
+        }
+    return 0;
+}
+/* word_embed(pooled) + lvl_pos, rows duplicated for CFG (var.py:186-187; var.py:206-207 for teacher forcing) */
+int varref_word_embed_f32(const float* pooled, const float* word_w, const float* word_b, const float* lvl_pos,
+                          float* x_out, int B, int lq, int C, int Cv) {
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int t = 0; t < lq; ++t)
+            for (int n = 0; n < C; ++n) {
+                float acc = 0.0f;
+                for (int c = 0; c < Cv; ++c) acc = vm_fma(pooled[((int64_t)b * lq + t) * Cv + c], word_w[(int64_t)n * Cv + c], acc);
+                float v = (acc + word_b[n]) + lvl_pos[(int64_t)t * C + n];
+                x_out[((int64_t)b * lq + t) * C + n] = v;
+                x_out[((int64_t)(b + B) * lq + t) * C + n] = v;
             }
     return 0;
 }
@@ -452,7 +496,8 @@ int varref_first_map_f32(const float* class_emb, const int64_t* labels, int num_
  * re-laid as [3][3][Cin][Cout] so the co loop vectorises; each out element is one (ky,kx,ci)-ascending fma chain. */
 static void conv3x3_core(const float* in, const float* wt, const float* bias, const float* resid, float* out,
                          int B, int H, int W, int Cin, int Cout, int up2, int out_mode) {
-    int Hi = up2 ? H / 2 : H, Wi = up2 ? W / 2 : W;
+    /* up2: 0 plain, 1 input read through a nearest 2x upsampling, 3 stride-2 over an input padded (0,1,0,1) (Downsample2x) */
+    int Hi = up2 == 1 ? H / 2 : (up2 == 3 ? 2 * H : H), Wi = up2 == 1 ? W / 2 : (up2 == 3 ? 2 * W : W);
 #pragma omp parallel for collapse(2) schedule(static)
     for (int b = 0; b < B; ++b)
         for (int y = 0; y < H; ++y) {
@@ -460,10 +505,10 @@ static void conv3x3_core(const float* in, const float* wt, const float* bias, co
             for (int x = 0; x < W; ++x) {
                 for (int co = 0; co < Cout; ++co) acc[co] = 0.0f;
                 for (int ky = 0; ky < 3; ++ky) {
-                    int yy = y + ky - 1; if (yy < 0 || yy >= H) continue;
+                    int yy = up2 == 3 ? 2 * y + ky : y + ky - 1; if (yy < 0 || yy >= (up2 == 3 ? Hi : H)) continue;
                     for (int kx = 0; kx < 3; ++kx) {
-                        int xx = x + kx - 1; if (xx < 0 || xx >= W) continue;
-                        int sy = up2 ? yy >> 1 : yy, sx = up2 ? xx >> 1 : xx;     /* nearest 2x: src = dst // 2 */
+                        int xx = up2 == 3 ? 2 * x + kx : x + kx - 1; if (xx < 0 || xx >= (up2 == 3 ? Wi : W)) continue;
+                        int sy = up2 == 1 ? yy >> 1 : yy, sx = up2 == 1 ? xx >> 1 : xx;     /* nearest 2x: src = dst // 2 */
                         const float* ip = in + (((int64_t)b * Hi + sy) * Wi + sx) * Cin;
                         const float* wp = wt + ((int64_t)(ky * 3 + kx) * Cin) * Cout;
                         for (int ci = 0; ci < Cin; ++ci) {
@@ -497,6 +542,25 @@ int varref_conv3x3_nhwc_f32(const float* in, const float* w, const float* bias, 
             for (int ci = 0; ci < Cin; ++ci) wt[((int64_t)t * Cin + ci) * Cout + co] = w[((int64_t)co * 9 + t) * Cin + ci];
     conv3x3_core(in, wt, bias, resid, out, B, H, W, Cin, Cout, up2, out_mode);
     free(wt);
+    return 0;
+}
+
+/* Downsample2x (basic_vae.py:31-37): F.pad(x, (0,1,0,1)) + Conv2d(k=3, stride=2); in [B][2H][2W][Cin] -> out [B][H][W][Cout] */
+int varref_conv3x3_s2_nhwc_f32(const float* in, const float* w, const float* bias, float* out, int B, int H, int W, int Cin, int Cout) {
+    float* wt = (float*)malloc(sizeof(float) * 9 * (size_t)Cin * Cout);
+    for (int co = 0; co < Cout; ++co)
+        for (int t = 0; t < 9; ++t)
+            for (int ci = 0; ci < Cin; ++ci) wt[((int64_t)t * Cin + ci) * Cout + co] = w[((int64_t)co * 9 + t) * Cin + ci];
+    conv3x3_core(in, wt, bias, NULL, out, B, H, W, Cin, Cout, 3, 0);
+    free(wt);
+    return 0;
+}
+
+/* image NCHW -> channels-last, channel count zero-padded to Cpad */
+int varref_nchw_to_nhwc_pad_f32(const float* in, float* out, int B, int C, int HW, int Cpad) {
+    if (Cpad < C) return VARHIP_EINVAL;
+    for (int b = 0; b < B; ++b) for (int p = 0; p < HW; ++p) for (int c = 0; c < Cpad; ++c)
+        out[((int64_t)b * HW + p) * Cpad + c] = c < C ? in[((int64_t)b * C + c) * HW + p] : 0.0f;
     return 0;
 }
 

@@ -252,6 +252,47 @@ def test_wide_models_vs_oracle(width, heads, saln, pns):
     ok, m = util.diff_report(f'C={width} image vs oracle', img.cpu().numpy(), r['img'], atol=1e-5); print(m); assert ok, m
 
 
+def test_encode_side_and_teacher_forcing_vs_reference(golden_dir):
+    """SURVEY.md §8f row 3 on HIP: image -> encoder -> residual quantisation -> tokens -> teacher-forcing input -> VAR.forward logits,
+    through the public module API, against the reference's own outputs (tests/golden/encode_t_pn12345.npz)"""
+    import json
+    z = np.load(f'{golden_dir}/encode_t_pn12345.npz')
+    meta = json.loads(str(z['meta']))
+    from models import build_vae_var
+    from var_amd.detinit import fill_module_
+    with contextlib.redirect_stdout(io.StringIO()):
+        vae, var = build_vae_var(device='cuda', patch_nums=tuple(meta['patch_nums']), depth=meta['depth'], ch=meta['ch'])
+    fill_module_(var, meta['depth'], 0, 'var.'); fill_module_(vae, meta['depth'], 0, 'vae.')
+    var.eval(); var.cond_drop_rate = 0.0
+    img = torch.from_numpy(z['img']).cuda()
+    with torch.inference_mode():
+        f = vae.img_to_post(img)
+        idx = vae.img_to_idxBl(img)
+        fh = vae.img_to_fhat(img)
+        x_in = vae.quantize.idxBl_to_var_input(idx)
+        logits = var(torch.tensor(meta['labels'], device='cuda'), x_in)
+    ok, m = util.diff_report('encoder+quant_conv f vs reference', f.cpu().numpy(), z['f'], atol=5e-5, rtol=1e-4); print(m); assert ok, m
+    for si, i in enumerate(idx):
+        ok, m = util.diff_report(f'encode tokens s{si} vs reference', i.cpu().numpy().astype(np.int32), z[f'idx_s{si}']); print(m); assert ok, m
+    ok, m = util.diff_report('f_hat (last) vs reference', fh[-1].cpu().numpy(), z['f_hat_last'], atol=2e-5, rtol=1e-5); print(m); assert ok, m
+    ok, m = util.diff_report('teacher-forcing input vs reference', x_in.cpu().numpy(), z['var_input'], atol=2e-5, rtol=1e-5); print(m); assert ok, m
+    ok, m = util.diff_report('teacher-forced logits vs reference', logits.cpu().numpy(), z['logits'], atol=3e-4, rtol=1e-5); print(m); assert ok, m
+    # identity (i) of SURVEY.md §4 on the HIP path, bit-exact: teacher-forced logits on the tokens an AR run sampled == that run's conditional logits
+    z2, meta2 = util.load_case('t_pn12345')
+    img_ar, tr = hip_run(meta2, z2)
+    vae2, var2 = build_models(meta2)
+    var2.cond_drop_rate = 0.0
+    ms, cur = [], 0
+    for pn in meta2['patch_nums']:
+        ms.append(torch.cat(tr['idx'], 1)[:, cur:cur + pn * pn].cuda() if isinstance(tr['idx'][0], torch.Tensor) else torch.from_numpy(np.concatenate(tr['idx'], 1)[:, cur:cur + pn * pn]).cuda())
+        cur += pn * pn
+    with torch.inference_mode():
+        tf = var2(torch.tensor(meta2['labels'], device='cuda'), vae2.quantize.idxBl_to_var_input(ms)).cpu().numpy()
+    B = len(meta2['labels'])
+    ar = np.concatenate([lg[:B] for lg in tr['logits']], axis=1)
+    ok, m = util.diff_report('teacher-forced == AR conditional logits (exact)', tf, ar); print(m); assert ok, m
+
+
 def test_d16_batch64_properties():
     """BASELINE.json configs[1] at full size (d16, 10 scales, B=64): determinism and agreement of the first two images with the
     B=2 reference fixture when fed the same noise rows (batch-slice invariance at the headline shape)."""

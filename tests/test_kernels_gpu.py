@@ -217,6 +217,34 @@ def test_gumbel_softmax_quant_h_and_token_select_exact():
     assert np.array_equal(w, np.where(keep.astype(bool), gt, sm))
 
 
+def test_encode_side_kernels_exact():
+    """stride-2 conv (Downsample2x), padded NCHW->NHWC, area pool, word embed, residual quantiser step vs their CPU twins"""
+    from oracle.var_oracle import bicubic_taps
+    rng = np.random.default_rng(123)
+    for (B, H, W, Cin, Cout) in [(2, 8, 8, 32, 64), (1, 40, 24, 160, 160), (2, 5, 5, 64, 32)]:
+        x = rnd(rng, B, 2 * H, 2 * W, Cin); w = rnd(rng, Cout, 3, 3, Cin, scale=(1.0 / (9 * Cin)) ** 0.5); bias = rnd(rng, Cout, scale=0.1)
+        out = np.zeros((B, H, W, Cout), np.float32)
+        (g,), (r,) = both('conv3x3_s2_nhwc_f32', [x, w, bias, out, B, H, W, Cin, Cout], [3]); check(f'conv s2 {Cin}->{Cout} {H}x{W}', g, r)
+    img = rnd(rng, 2, 3, 30); o = np.zeros((2, 30, 16), np.float32)
+    (g,), (r,) = both('nchw_to_nhwc_pad_f32', [img, o, 2, 3, 30, 16], [1]); check('nchw_to_nhwc_pad', g, r)
+    assert np.array_equal(r[:, :, 3:], np.zeros((2, 30, 13), np.float32)) and np.array_equal(r[:, :, :3], img.transpose(0, 2, 1))
+    B, P, Cv, C = 3, 16, 32, 128
+    f = rnd(rng, B, P, P, Cv)
+    for pq in (1, 3, 5, 13, 16):
+        pooled = np.zeros((B, pq * pq, Cv), np.float32)
+        (g,), (r,) = both('area_pool_f32', [f, pooled, B, P, pq, Cv], [1]); check(f'area_pool ->{pq}', g, r)
+        ww, wb, lp = rnd(rng, C, Cv, scale=0.2), rnd(rng, C, scale=0.1), rnd(rng, pq * pq, C)
+        xo = np.zeros((2 * B * pq * pq, C), np.float32)
+        (g2,), (r2,) = both('word_embed_f32', [r, ww, wb, lp, xo, B, pq * pq, C, Cv], [4]); check(f'word_embed lq={pq * pq}', g2, r2)
+    V, pn = 4096, 6
+    idx = rng.integers(0, V, (B, pn * pn)).astype(np.int64); cb = rnd(rng, V, Cv); pw = rnd(rng, Cv, 3, 3, Cv, scale=0.1); pb = rnd(rng, Cv, scale=0.05)
+    f_hat, f_rest, up = rnd(rng, B, P, P, Cv), rnd(rng, B, P, P, Cv), np.zeros((B, P, P, Cv), np.float32)
+    ti, tw = bicubic_taps(pn, P)
+    (gh, gr), (rh, rr) = both('quant_residual_f32', [idx, cb, ti, tw, pw, pb, 0.5, up, f_hat, f_rest, B, pn, P, Cv], [8, 9])
+    check('quant_residual f_hat', gh, rh); check('quant_residual f_rest', gr, rr)
+    assert np.allclose((rh - f_hat), -(rr - f_rest), atol=1e-6)
+
+
 def test_prologue_and_small_ops_exact():
     rng = np.random.default_rng(3)
     B, C, L, S = 3, 128, 14, 3

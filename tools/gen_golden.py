@@ -195,6 +195,29 @@ def run_more_smooth():
     print(f'[gen_golden] more_smooth_t_pn12345: img mean {img.mean():.4f}', flush=True)
 
 
+def run_encode():
+    """encode side + teacher forcing: VQVAE.img_to_post / img_to_idxBl (vqvae.py:65-75), quantize.idxBl_to_var_input
+    (quant.py:169-184) and VAR.forward (var.py:192-234, cond_drop_rate 0) on a seeded random image"""
+    cfg = dict(CASES['t_pn12345'])
+    vae, var = build_reference(cfg)
+    var.cond_drop_rate = 0.0
+    P = cfg['patch_nums'][-1]
+    g = torch.Generator(); g.manual_seed(31)
+    img = torch.rand(2, 3, 16 * P, 16 * P, generator=g) * 2 - 1
+    lab = torch.tensor(cfg['labels'])
+    with torch.inference_mode():
+        f = vae.img_to_post(img)
+        idx = vae.img_to_idxBl(img)
+        fh = vae.img_to_fhat(img)
+        x_in = vae.quantize.idxBl_to_var_input(idx)
+        logits = var(lab, x_in)
+    rec = dict(img=img.numpy(), f=f.numpy(), var_input=x_in.numpy(), logits=logits.numpy(), f_hat_last=fh[-1].numpy(),
+               meta=np.array(json.dumps(dict(cfg))))
+    for si, i in enumerate(idx): rec[f'idx_s{si}'] = i.numpy().astype(np.int32)
+    np.savez_compressed(os.path.join(GOLD, 'encode_t_pn12345.npz'), **rec)
+    print(f'[gen_golden] encode_t_pn12345: f std {f.std():.3f}, logits std {logits.std():.3f}', flush=True)
+
+
 def run_nearest_code():
     """A17 fixture: VectorQuantizer2.f_to_idxBl_or_fhat (reference models/quant.py:135-166) on a random feature map."""
     cfg = CASES['t_pn12345']
@@ -250,6 +273,7 @@ def main():
         run_case(name, cfg)
     if not args.only or 'inpaint' in args.only: run_inpaint()
     if not args.only or 'more_smooth' in args.only: run_more_smooth()
+    if not args.only or 'encode' in args.only: run_encode()
     if not args.only or 'nearest_code' in args.only: run_nearest_code()
     if not args.only or 'sampler' in args.only: run_sampler_vectors()
 

@@ -33,6 +33,11 @@ SIGNATURES = {
     'nhwc_to_nchw_f32':  [P, P, I, I, I],
     'nearest_code_f32':  [P, P, P, I, I, I],
     'token_select_i64':  [P, P, P, P, L],
+    'conv3x3_s2_nhwc_f32': [P, P, P, P, I, I, I, I, I],
+    'nchw_to_nhwc_pad_f32': [P, P, I, I, I, I],
+    'area_pool_f32':     [P, P, I, I, I, I],
+    'word_embed_f32':    [P, P, P, P, P, I, I, I, I],
+    'quant_residual_f32': [P, P, P, P, P, P, F, P, P, P, I, I, I, I],
     'upconv_pack_f32':   [P, P, I, I],
     'upconv_phase_f32':  [P, P, P, P, I, I, I, I, I],
     'quant_accum_h_f32': [P, P, P, P, P, F, P, P, I, I, I, I],

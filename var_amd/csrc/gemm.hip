@@ -96,11 +96,14 @@ __global__ void __launch_bounds__(256) k_mfma_gemm(GemmP p) {
                 int yy, xx;
                 if (p.up2 == 2) {       // phase (bz>>1, bz&1) of a nearest-2x + 3x3 conv folded into a 2x2 conv on the low-res map
                     yy = a_y[i] + (tap >> 1) - 1 + (bz >> 1); xx = a_x[i] + (tap & 1) - 1 + (bz & 1);
+                } else if (p.up2 == 3) { // stride-2 conv over an input padded by one zero row/column at the bottom/right (Downsample2x)
+                    const int ky = tap / 3, kx = tap - ky * 3;
+                    yy = 2 * a_y[i] + ky; xx = 2 * a_x[i] + kx;
                 } else {
                     const int ky = tap / 3, kx = tap - ky * 3;
                     yy = a_y[i] + ky - 1; xx = a_x[i] + kx - 1;
                 }
-                ok = ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd;
+                ok = ok && yy >= 0 && xx >= 0 && (p.up2 == 3 ? (yy < p.Hi && xx < p.Wi) : (yy < p.H && xx < p.Wd));
                 const int sy = p.up2 == 1 ? (yy >> 1) : yy, sx = p.up2 == 1 ? (xx >> 1) : xx;
                 src = Ab + (((int64_t)a_b[i] * p.Hi + (ok ? sy : 0)) * p.Wi + (ok ? sx : 0)) * p.Cin + ci0 + a_c[i] * 8;
             } else {
@@ -333,6 +336,27 @@ extern "C" int varhip_conv3x3_nhwc_f32(const float* in, const float* w, const fl
     const double npix = (double)B * H * W;
     VhScope scope(VH_FAM_CONV, (hipStream_t)stream, 2.0 * npix * Cout * 9.0 * Cin,
                   4.0 * (npix * Cin / (up2 ? 4.0 : 1.0) + npix * Cout * (resid ? 2.0 : 1.0) + 9.0 * Cin * Cout));
+    hipStream_t s = (hipStream_t)stream;
+    if (Cout % 160 == 0) return launch_gemm<1, 5, 4, 1, 16, true>(p, 1, s);
+    if (Cout % 128 == 0) return launch_gemm<1, 4, 4, 1, 16, true>(p, 1, s);
+    if (Cout % 64 == 0) return launch_gemm<1, 2, 4, 1, 16, true>(p, 1, s);
+    return launch_gemm<1, 1, 4, 1, 16, true>(p, 1, s);
+}
+
+// ---- Downsample2x of the encoder (basic_vae.py:31-37): F.pad(x, (0,1,0,1)) then Conv2d(k=3, stride=2, padding=0) -------------
+extern "C" int varhip_conv3x3_s2_nhwc_f32(const float* in, const float* w, const float* bias, float* out,
+                                          int B, int H, int W, int Cin, int Cout, varhip_stream_t stream) {
+    // in: [B][2H][2W][Cin], out: [B][H][W][Cout]
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (Cin & 15) || !bias) return VARHIP_EINVAL;
+    if ((int64_t)B * H * W >= (1ll << 31)) return VARHIP_EINVAL;
+    GemmP p{};
+    p.A = in; p.W = w; p.bias = bias; p.out = out;
+    p.ldw = 9ll * Cin; p.ldo = Cout; p.ldr = Cout;
+    p.M = B * H * W; p.N = Cout; p.K = 9 * Cin; p.epi = VARHIP_EPI_NONE; p.rows_per_group = 1;
+    p.H = H; p.Wd = W; p.Cin = Cin; p.up2 = 3; p.out_mode = 0; p.Hi = 2 * H; p.Wi = 2 * W;
+    p.evec = !((Cout & 3) || ((uintptr_t)out & 15) || ((uintptr_t)bias & 15));
+    const double npix = (double)B * H * W;
+    VhScope scope(VH_FAM_CONV, (hipStream_t)stream, 2.0 * npix * Cout * 9.0 * Cin, 4.0 * (npix * 4 * Cin + npix * Cout + 9.0 * Cin * Cout));
     hipStream_t s = (hipStream_t)stream;
     if (Cout % 160 == 0) return launch_gemm<1, 5, 4, 1, 16, true>(p, 1, s);
     if (Cout % 128 == 0) return launch_gemm<1, 4, 4, 1, 16, true>(p, 1, s);

@@ -116,6 +116,59 @@ extern "C" int varhip_next_map_f32(const float* f_hat, const float* word_w, cons
     return vh_launch_status();
 }
 
+// ---- encode side / teacher forcing (quant.py:135-184) -----------------------------------------------------------------------
+extern "C" int varhip_area_pool_f32(const float* f, float* pooled, int B, int P, int pq, int Cv, varhip_stream_t stream) {
+    if (B <= 0 || P <= 0 || pq <= 0 || pq > P || Cv <= 0) return VARHIP_EINVAL;
+    const int64_t t1 = (int64_t)B * pq * pq * Cv;
+    VhScope sc(VH_FAM_OTHER, (hipStream_t)stream, 0, 8.0 * B * P * P * Cv);
+    hipLaunchKernelGGL(k_area_pool, dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, f, pooled, B, P, pq, Cv);
+    return vh_launch_status();
+}
+
+extern "C" int varhip_word_embed_f32(const float* pooled, const float* word_w, const float* word_b, const float* lvl_pos,
+                                     float* x_out, int B, int lq, int C, int Cv, varhip_stream_t stream) {
+    // x[b][t][:] = word_w . pooled[b][t][:] + word_b + lvl_pos[t][:]; writes rows [0, B*lq) and the CFG copy [B*lq, 2*B*lq)
+    if (B <= 0 || lq <= 0 || C <= 0 || Cv <= 0) return VARHIP_EINVAL;
+    const int64_t t2 = (int64_t)B * lq * C;
+    VhScope sc(VH_FAM_OTHER, (hipStream_t)stream, 2.0 * t2 * Cv, 8.0 * t2);
+    hipLaunchKernelGGL(k_word_embed, dim3((unsigned)((t2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pooled, word_w, word_b, lvl_pos, x_out, B, lq, C, Cv);
+    return vh_launch_status();
+}
+
+// residual quantisation step: like varhip_quant_accum_f32, and the same h is subtracted from the running residual f_rest
+__global__ void k_phi_accum_rest(const float* __restrict__ up, const float* __restrict__ phi_w, const float* __restrict__ phi_b, float ratio, float keep,
+                                 float* __restrict__ f_hat, float* __restrict__ f_rest, int B, int P, int Cv) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * P * P * Cv) return;
+    const int co = (int)(i % Cv); int64_t t = i / Cv; const int x = (int)(t % P); t /= P; const int y = (int)(t % P); const int b = (int)(t / P);
+    float acc = 0.f;
+    for (int ky = 0; ky < 3; ++ky) {
+        const int yy = y + ky - 1; if (yy < 0 || yy >= P) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int xx = x + kx - 1; if (xx < 0 || xx >= P) continue;
+            const float* u = up + (((int64_t)b * P + yy) * P + xx) * Cv;
+            const float* w = phi_w + (((int64_t)co * 3 + ky) * 3 + kx) * Cv;
+            for (int ci = 0; ci < Cv; ++ci) acc = vm_fma(u[ci], w[ci], acc);
+        }
+    }
+    const float conv = acc + phi_b[co];
+    const float hmix = up[i] * keep + conv * ratio;
+    f_hat[i] = f_hat[i] + hmix;
+    f_rest[i] = f_rest[i] - hmix;
+}
+extern "C" int varhip_quant_residual_f32(const int64_t* idx, const float* codebook, const int32_t* tap_idx, const float* tap_w,
+                                         const float* phi_w, const float* phi_b, float ratio, float* up, float* f_hat, float* f_rest,
+                                         int B, int pn, int P, int Cv, varhip_stream_t stream) {
+    if (B <= 0 || pn <= 0 || P <= 0 || pn > P || Cv <= 0 || Cv > 64 || !f_rest) return VARHIP_EINVAL;
+    if (pn != P && (!tap_idx || !tap_w)) return VARHIP_EINVAL;
+    const int64_t tot = (int64_t)B * P * P * Cv;
+    VhScope sc(VH_FAM_OTHER, (hipStream_t)stream, 2.0 * tot * 9 * Cv, 24.0 * tot);
+    const unsigned blocks = (unsigned)((tot + 255) / 256);
+    hipLaunchKernelGGL(k_gather_up<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, idx, codebook, tap_idx, tap_w, up, B, pn, P, Cv);
+    hipLaunchKernelGGL(k_phi_accum_rest, dim3(blocks), dim3(256), 0, (hipStream_t)stream, up, phi_w, phi_b, ratio, 1.0f - ratio, f_hat, f_rest, B, P, Cv);
+    return vh_launch_status();
+}
+
 __global__ void k_token_select(const uint8_t* __restrict__ keep, const int64_t* __restrict__ gt, const int64_t* __restrict__ sampled, int64_t* __restrict__ out, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = keep[i] ? gt[i] : sampled[i];

@@ -274,6 +274,21 @@ extern "C" int varhip_nchw_to_nhwc_f32(const float* in, float* out, int B, int C
     hipLaunchKernelGGL(k_nchw_to_nhwc, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out, C, HW, tot);
     return vh_launch_status();
 }
+// image (B,3,H,W) -> channels-last with the channel count padded by zeros (the conv kernels want Cin % 16 == 0)
+__global__ void k_nchw_to_nhwc_pad(const float* __restrict__ in, float* __restrict__ out, int C, int HW, int Cpad, int64_t tot) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // index into out [B][HW][Cpad]
+    if (i >= tot) return;
+    const int c = (int)(i % Cpad); const int64_t bp = i / Cpad; const int p = (int)(bp % HW); const int64_t b = bp / HW;
+    out[i] = c < C ? in[(b * C + c) * HW + p] : 0.f;
+}
+extern "C" int varhip_nchw_to_nhwc_pad_f32(const float* in, float* out, int B, int C, int HW, int Cpad, varhip_stream_t stream) {
+    if (B <= 0 || C <= 0 || HW <= 0 || Cpad < C) return VARHIP_EINVAL;
+    const int64_t tot = (int64_t)B * Cpad * HW;
+    VhScope sc(VH_FAM_OTHER, (hipStream_t)stream, 0, 8.0 * tot);
+    hipLaunchKernelGGL(k_nchw_to_nhwc_pad, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out, C, HW, Cpad, tot);
+    return vh_launch_status();
+}
+
 extern "C" int varhip_nhwc_to_nchw_f32(const float* in, float* out, int B, int C, int HW, varhip_stream_t stream) {
     if (B <= 0 || C <= 0 || HW <= 0) return VARHIP_EINVAL;
     const int64_t tot = (int64_t)B * C * HW;

@@ -55,8 +55,10 @@ def _chk(t: torch.Tensor, name: str) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
-class DecoderEngine:
-    """VQVAE.fhat_to_img on HIP kernels (reference vqvae.py:62-63, basic_vae.py:163-226)."""
+class _VaeOps:
+    """channels-last building blocks shared by the decoder and encoder engines (reference basic_vae.py:18-92)"""
+
+    PREFIXES = ()
 
     def __init__(self, vae):
         self.vae = vae
@@ -66,22 +68,38 @@ class DecoderEngine:
     def _signature(self):
         return tuple((p.data_ptr(), p._version) for p in self.vae.parameters())
 
-    def refresh(self):
-        sig = self._signature()
-        if sig == self._sig:
-            return
-        sd = {k: v for k, v in self.vae.state_dict().items()}
+    def _pack(self):
+        """our copies of the weights this engine uses: 3x3 kernels re-laid [Cout][3][3][Cin] (Cin zero-padded to a multiple of 16),
+        1x1 kernels as [Cout][Cin] matrices"""
         w = {}
-        for k, v in sd.items():
-            if k.startswith('encoder.') or k.startswith('quant_conv.') or not torch.is_floating_point(v):
+        for k, v in self.vae.state_dict().items():
+            if not k.startswith(self.PREFIXES) or not torch.is_floating_point(v):
                 continue
             v = _chk(v.detach(), k)
             if v.dim() == 4 and v.shape[-1] == 3:
-                w[k] = v.permute(0, 2, 3, 1).contiguous()          # [Cout][Cin][3][3] -> [Cout][3][3][Cin]
+                v = v.permute(0, 2, 3, 1).contiguous()               # [Cout][Cin][3][3] -> [Cout][3][3][Cin]
+                if v.shape[3] % 16:
+                    pad = torch.zeros(v.shape[0], 3, 3, (v.shape[3] + 15) // 16 * 16, dtype=v.dtype, device=v.device)
+                    pad[..., :v.shape[3]] = v
+                    v = pad
+                w[k] = v
             elif v.dim() == 4:
                 w[k] = v.reshape(v.shape[0], v.shape[1])            # 1x1 conv == linear
             else:
                 w[k] = v
+        return w
+
+
+class DecoderEngine(_VaeOps):
+    """VQVAE.fhat_to_img on HIP kernels (reference vqvae.py:62-63, basic_vae.py:163-226)."""
+
+    PREFIXES = ('decoder.', 'post_quant_conv.')
+
+    def refresh(self):
+        sig = self._signature()
+        if sig == self._sig:
+            return
+        w = self._pack()
         for k in [k for k in w if k.endswith('.upsample.conv.weight')]:        # Upsample2x convs: pre-summed 2x2 phase weights
             cout, _, _, cin = w[k].shape
             wp = torch.empty(4, cout, 2, 2, cin, dtype=torch.float32, device=w[k].device)
@@ -185,6 +203,125 @@ class DecoderEngine:
                 h = up
         h = self.gn(h, 'decoder.norm_out', B, Hh * Ww, True)
         return self.conv3(h, 'decoder.conv_out', B, Hh, Ww, out_mode=1 if denorm else 2)
+
+
+class QuantizerEngine:
+    """Encode-side methods of VectorQuantizer2 on HIP: f_to_idxBl_or_fhat (quant.py:135-166) and idxBl_to_var_input (quant.py:169-184)"""
+
+    def __init__(self, quant):
+        self.quant = quant
+        self._sig = None
+
+    def refresh(self):
+        q = self.quant
+        sig = tuple((p.data_ptr(), p._version) for p in q.parameters())
+        if sig == self._sig:
+            return
+        if q.using_znorm:
+            raise NotImplementedError('using_znorm=True (cosine nearest-code) is not on the HIP path')
+        self.codebook = _chk(q.embedding.weight.detach(), 'codebook')
+        self.phi = [(_chk(p.weight.detach(), 'phi').permute(0, 2, 3, 1).contiguous(), _chk(p.bias.detach(), 'phi'), float(p.resi_ratio))
+                    for p in q.quant_resi.phis()]
+        self._taps = {}
+        self._sig = sig
+
+    def taps(self, pn, P, dev):
+        if (pn, P) not in self._taps:
+            ti, tw = bicubic_taps(pn, P)
+            self._taps[(pn, P)] = (torch.from_numpy(ti).to(dev), torch.from_numpy(tw).to(dev))
+        return self._taps[(pn, P)]
+
+    @torch.no_grad()
+    def quantize(self, f_nhwc: torch.Tensor, to_fhat: bool, patch_nums):
+        """residual quantisation scale by scale (quant.py:147-164): idx lists (B, pn^2) int64, or the cumulative f_hat's (NCHW)"""
+        self.refresh()
+        B, P, _, Cv = f_nhwc.shape
+        dev = f_nhwc.device
+        f_rest = f_nhwc.clone()
+        f_hat = torch.zeros_like(f_rest)
+        up = torch.empty_like(f_rest)
+        S, out = len(patch_nums), []
+        for si, pn in enumerate(patch_nums):
+            if si != S - 1:
+                z = torch.empty((B, pn * pn, Cv), dtype=torch.float32, device=dev)
+                hip.call('area_pool_f32', f_rest, z, B, P, pn, Cv)
+            else:
+                z = f_rest
+            idx = torch.empty(B * pn * pn, dtype=torch.int64, device=dev)
+            hip.call('nearest_code_f32', z, self.codebook, idx, B * pn * pn, self.codebook.shape[0], Cv)
+            ti, tw = self.taps(pn, P, dev) if pn != P else (None, None)
+            pw, pb, ratio = self.phi[phi_index(si, S, len(self.phi))]
+            hip.call('quant_residual_f32', idx, self.codebook, ti, tw, pw, pb, ratio, up, f_hat, f_rest, B, pn, P, Cv)
+            out.append(f_hat.permute(0, 3, 1, 2).contiguous() if to_fhat else idx.view(B, pn * pn))
+        return out
+
+    @torch.no_grad()
+    def var_input(self, idx_list, patch_nums) -> torch.Tensor:
+        """teacher-forcing input (B, L - first_l, Cvae) of VAR.forward from ground-truth token maps (quant.py:169-184)"""
+        self.refresh()
+        B, P, Cv, S = idx_list[0].shape[0], patch_nums[-1], self.codebook.shape[1], len(patch_nums)
+        dev = idx_list[0].device
+        f_hat = torch.zeros((B, P, P, Cv), dtype=torch.float32, device=dev)
+        up = torch.empty_like(f_hat)
+        L = sum(p * p for p in patch_nums)
+        out = torch.empty((B, L - patch_nums[0] ** 2, Cv), dtype=torch.float32, device=dev)
+        cur = 0
+        for si in range(S - 1):
+            pn, pq = patch_nums[si], patch_nums[si + 1]
+            ti, tw = self.taps(pn, P, dev) if pn != P else (None, None)
+            pw, pb, ratio = self.phi[phi_index(si, S, len(self.phi))]
+            hip.call('quant_accum_f32', idx_list[si].to(torch.int64).contiguous(), self.codebook, ti, tw, pw, pb, ratio, up, f_hat, B, pn, P, Cv)
+            pooled = torch.empty((B, pq * pq, Cv), dtype=torch.float32, device=dev)
+            hip.call('area_pool_f32', f_hat, pooled, B, P, pq, Cv)
+            out[:, cur:cur + pq * pq] = pooled
+            cur += pq * pq
+        return out
+
+
+class EncoderEngine(DecoderEngine):
+    """Encoder + quant_conv on HIP (reference vqvae.py:65-75 img_to_*: basic_vae.py:99-160).  Inherits the channels-last conv /
+    GroupNorm / attention building blocks of DecoderEngine."""
+
+    PREFIXES = ('encoder.', 'quant_conv.')
+
+    def refresh(self):
+        sig = self._signature()
+        if sig == self._sig:
+            return
+        self.w = self._pack()
+        self.nlev = 1 + max(int(k.split('.')[2]) for k in self.w if k.startswith('encoder.down.'))
+        self._sig = sig
+
+    def conv_s2(self, x, key, B, Hh, Ww):
+        wt = self.w[key + '.weight']
+        Cout, Cin = wt.shape[0], wt.shape[3]
+        out = torch.empty((B, Hh, Ww, Cout), dtype=torch.float32, device=x.device)
+        hip.call('conv3x3_s2_nhwc_f32', x, wt, self.w[key + '.bias'], out, B, Hh, Ww, Cin, Cout)
+        return out
+
+    @torch.no_grad()
+    def encode(self, img: torch.Tensor) -> torch.Tensor:
+        """img (B,3,H,W) fp32 in [-1,1] -> f (B, H/16, W/16, Cvae) channels-last == quant_conv(encoder(img))"""
+        self.refresh()
+        B, Ci, Hh, Ww = img.shape
+        cin_pad = self.w['encoder.conv_in.weight'].shape[3]
+        x = torch.empty((B, Hh, Ww, cin_pad), dtype=torch.float32, device=img.device)
+        hip.call('nchw_to_nhwc_pad_f32', img.contiguous(), x, B, Ci, Hh * Ww, cin_pad)
+        h = self.conv3(x, 'encoder.conv_in', B, Hh, Ww)
+        for lev in range(self.nlev):
+            for ib in range(2):
+                h = self.resblock(h, f'encoder.down.{lev}.block.{ib}', B, Hh, Ww)
+                if f'encoder.down.{lev}.attn.{ib}.norm.weight' in self.w:
+                    h = self.attnblock(h, f'encoder.down.{lev}.attn.{ib}', B, Hh, Ww)
+            if lev != self.nlev - 1:
+                Hh, Ww = Hh // 2, Ww // 2
+                h = self.conv_s2(h, f'encoder.down.{lev}.downsample.conv', B, Hh, Ww)
+        h = self.resblock(h, 'encoder.mid.block_1', B, Hh, Ww)
+        h = self.attnblock(h, 'encoder.mid.attn_1', B, Hh, Ww)
+        h = self.resblock(h, 'encoder.mid.block_2', B, Hh, Ww)
+        h = self.conv3(self.gn(h, 'encoder.norm_out', B, Hh * Ww, True), 'encoder.conv_out', B, Hh, Ww)
+        return self.conv3(h, 'quant_conv', B, Hh, Ww)
+
 
 
 class SamplingEngine:
@@ -397,6 +534,74 @@ class SamplingEngine:
         if not decode:
             return ws['f_hat'].permute(0, 3, 1, 2).contiguous()
         return self.dec.decode_nhwc(ws['f_hat'])                          # var.py:190
+
+    # -- teacher-forced logits (VAR.forward without autograd) ------------------------------------------------------------
+    @torch.no_grad()
+    def teacher_forced_logits(self, label_B: torch.Tensor, x_BLCv_wo_first_l: Optional[torch.Tensor]) -> torch.Tensor:
+        """logits (B, L, V) of VAR.forward (reference var.py:192-234) for given next-scale inputs, computed scale by scale over the
+        KV cache instead of one masked pass: the cache holds exactly the scales <= the current one, which is what the block-causal
+        mask `attn_bias_for_masking` allows (SURVEY.md §4 identity (i): identical to 3e-8 in the reference itself).
+        No CFG doubling: B rows.  label_B may contain num_classes (dropped condition)."""
+        var = self.var
+        self.refresh()
+        w = self.w
+        R = int(label_B.numel())                               # rows: one per image, no CFG pair
+        dev = var.pos_start.device
+        C, H, V, Cv, L = var.C, var.num_heads, var.V, var.Cvae, var.L
+        if int(label_B.min()) < 0 or int(label_B.max()) > var.num_classes:
+            raise ValueError(f'labels must lie in [0, {var.num_classes}]')
+        lmax = max(p * p for p in var.patch_nums)
+        hid = var.blocks[0].ffn.fc1.weight.shape[0]
+        ws = self._ws_tf.get(R) if hasattr(self, '_ws_tf') else None
+        if ws is None or ws['dev'] != dev:
+            e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+            M = R * lmax
+            # x is written by first_map_f32 / word_embed_f32, which also emit the CFG copy of every row (unused here): room for 2x
+            ws = dict(dev=dev, x=e(2 * M, C), x2=e(M, C), xn=e(M, C), qkv=e(M, 3 * C), q=e(M, C), att=e(M, C), hid=e(M, hid), lg=e(R * lmax, V),
+                      lvl_pos=e(L, C), cond=e(2 * R, C), cond_silu=e(2 * R, C), hn=e(R, 2 * C), ada=e(var.depth, R, 6 * C),
+                      shared=e(R, 6 * C) if var.shared_aln else None,
+                      kc=[torch.zeros(R, H, L, 64, dtype=torch.float32, device=dev) for _ in range(var.depth)],
+                      vc=[torch.zeros(R, H, L, 64, dtype=torch.float32, device=dev) for _ in range(var.depth)])
+            self._ws_tf = {R: ws}
+        lab = label_B.to(dev).long().contiguous()
+        hip.call('lvl_pos_f32', w['lvl_embed'], w['lvl_1L'], w['pos_1LC'], ws['lvl_pos'], L, C)
+        hip.call('first_map_f32', w['class_emb'], lab, var.num_classes, w['pos_start'], ws['lvl_pos'], ws['cond'], ws['x'], R, C, var.first_l)
+        hip.call('silu_f32', ws['cond'], ws['cond_silu'], R * C)
+        if var.shared_aln:
+            self.gemm(ws['cond_silu'], w['sal_w'], w['sal_b'], ws['shared'], R)
+        for bi, blk in enumerate(w['blocks']):
+            if var.shared_aln:
+                hip.call('add_bcast_f32', blk['gss'], ws['shared'], ws['ada'][bi], R, 6 * C)
+            else:
+                self.gemm(ws['cond_silu'], blk['ada_w'], blk['ada_b'], ws['ada'][bi], R)
+        self.gemm(ws['cond_silu'], w['hn_w'], w['hn_b'], ws['hn'], R)
+        out = torch.empty(R, L, V, dtype=torch.float32, device=dev)
+        x, x2 = ws['x'], ws['x2']
+        cur = 0
+        xin = None if x_BLCv_wo_first_l is None else x_BLCv_wo_first_l.to(dev, torch.float32).contiguous()
+        for si, pn in enumerate(var.patch_nums):
+            l = pn * pn
+            M = R * l
+            if si > 0:                                           # word_embed(teacher-forcing input) + lvl_pos  (var.py:206-207)
+                seg = xin[:, cur - var.first_l:cur - var.first_l + l].contiguous()
+                hip.call('word_embed_f32', seg, w['word_w'], w['word_b'], ws['lvl_pos'][cur:], x, R, l, C, Cv)
+            for bi, blk in enumerate(w['blocks']):
+                ada = ws['ada'][bi]
+                g1, g2, s1, s2, h1, h2 = (ada[:, i * C:] for i in range(6))
+                hip.call('ln_modulate_f32', x, s1, 6 * C, h1, 6 * C, ws['xn'], M, C, l, var.norm_eps)
+                self.gemm(ws['xn'], blk['qkv_w'], blk['qkv_b'], ws['qkv'], M)
+                hip.call('qkv_prep_f32', ws['qkv'], blk['smul'], blk['plain_scale'], int(blk['l2']), ws['q'], ws['kc'][bi], ws['vc'][bi], R, l, H, cur, L)
+                hip.call('attn_cached_f32', ws['q'], ws['kc'][bi], ws['vc'][bi], ws['att'], R, l, H, cur + l, L)
+                self.gemm(ws['att'], blk['proj_w'], blk['proj_b'], x2, M, EPI_RESID, resid=x, gamma=g1, ldg=6 * C, rpg=l)
+                hip.call('ln_modulate_f32', x2, s2, 6 * C, h2, 6 * C, ws['xn'], M, C, l, var.norm_eps)
+                self.gemm(ws['xn'], blk['fc1_w'], blk['fc1_b'], ws['hid'], M, EPI_GELU)
+                self.gemm(ws['hid'], blk['fc2_w'], blk['fc2_b'], x, M, EPI_RESID, resid=x2, gamma=g2, ldg=6 * C, rpg=l)
+            hn = ws['hn']
+            hip.call('ln_modulate_f32', x, hn, 2 * C, hn[:, C:], 2 * C, ws['xn'], M, C, l, var.norm_eps)
+            self.gemm(ws['xn'], w['head_w'], w['head_b'], ws['lg'], M)
+            out[:, cur:cur + l] = ws['lg'][:M].view(R, l, V)
+            cur += l
+        return out
 
     # -- model arithmetic (for bench.py's roofline) -------------------------------------------------------------------
     def flops_per_image(self) -> float:

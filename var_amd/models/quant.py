@@ -128,9 +128,28 @@ class VectorQuantizer2(nn.Module):
                 outs.append(f_hat)
         return outs[-1] if last_one else outs
 
+    # ---- HIP routing of the encode-side methods (inference on fp32 CUDA tensors); everything else takes the PyTorch code below ----
+    def hip_engine(self):
+        if getattr(self, '_hip_engine', None) is None:
+            from ..engine import QuantizerEngine
+            object.__setattr__(self, '_hip_engine', QuantizerEngine(self))
+        return self._hip_engine
+
+    def _hip_eligible(self, t: torch.Tensor, v_patch_nums=None) -> bool:
+        pns = v_patch_nums or self.v_patch_nums
+        return (t.is_cuda and not torch.is_grad_enabled() and not self.using_znorm and self.prog_si < 0
+                and self.embedding.weight.dtype == torch.float32 and all(isinstance(p, int) for p in pns))
+
     def f_to_idxBl_or_fhat(self, f_BChw: torch.Tensor, to_fhat: bool, v_patch_nums: Optional[Sequence[Union[int, Tuple[int, int]]]] = None):
         """residual quantisation of an encoder feature map, scale by scale (reference quant.py:135-166)"""
         B, C, H, W = f_BChw.shape
+        if f_BChw.dtype == torch.float32 and H == W and self._hip_eligible(f_BChw, v_patch_nums):
+            from .. import hip
+            pns = tuple(v_patch_nums or self.v_patch_nums)
+            assert pns[-1] == H, f'{pns[-1]=} != ({H=}, {W=})'
+            nhwc = torch.empty(B, H, W, C, dtype=torch.float32, device=f_BChw.device)
+            hip.call('nchw_to_nhwc_f32', f_BChw.contiguous(), nhwc, B, C, H * W)
+            return self.hip_engine().quantize(nhwc, to_fhat, pns)
         f_rest = f_BChw.detach().clone()
         f_hat = torch.zeros_like(f_rest)
         hws = [(pn, pn) if isinstance(pn, int) else (pn[0], pn[1]) for pn in (v_patch_nums or self.v_patch_nums)]
@@ -147,6 +166,8 @@ class VectorQuantizer2(nn.Module):
 
     def idxBl_to_var_input(self, gt_ms_idx_Bl: List[torch.Tensor]) -> torch.Tensor:
         """teacher-forcing input of VAR.forward (reference quant.py:169-184)"""
+        if len(gt_ms_idx_Bl) == len(self.v_patch_nums) and self._hip_eligible(gt_ms_idx_Bl[0]):
+            return self.hip_engine().var_input(list(gt_ms_idx_Bl), tuple(self.v_patch_nums))
         B, C, SN = gt_ms_idx_Bl[0].shape[0], self.Cvae, len(self.v_patch_nums)
         H = W = self.v_patch_nums[-1]
         f_hat = gt_ms_idx_Bl[0].new_zeros(B, C, H, W, dtype=torch.float32)

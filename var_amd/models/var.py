@@ -108,6 +108,11 @@ class VAR(nn.Module):
 
     def forward(self, label_B: torch.LongTensor, x_BLCv_wo_first_l: torch.Tensor) -> torch.Tensor:
         """logits (B, L, V) for teacher-forced inputs (B, L-first_l, Cvae); block-causal mask instead of a KV cache"""
+        if (not torch.is_grad_enabled() and self.prog_si < 0 and self.lvl_1L.is_cuda and self.head.weight.dtype == torch.float32
+                and x_BLCv_wo_first_l is not None and x_BLCv_wo_first_l.shape[1] == self.L - self.first_l):
+            # inference (no autograd): scale-by-scale over the KV cache on the HIP kernels, fp32, same label dropping as below
+            label_B = torch.where(torch.rand(label_B.shape[0], device=label_B.device) < self.cond_drop_rate, self.num_classes, label_B)
+            return self.engine().teacher_forced_logits(label_B, x_BLCv_wo_first_l)
         bg, ed = self.begin_ends[self.prog_si] if self.prog_si >= 0 else (0, self.L)
         B = x_BLCv_wo_first_l.shape[0]
         with torch.autocast(device_type=x_BLCv_wo_first_l.device.type, enabled=False):

@@ -30,6 +30,7 @@ class VQVAE(nn.Module):
         self.quant_conv = nn.Conv2d(self.Cvae, self.Cvae, quant_conv_ks, stride=1, padding=quant_conv_ks // 2)
         self.post_quant_conv = nn.Conv2d(self.Cvae, self.Cvae, quant_conv_ks, stride=1, padding=quant_conv_ks // 2)
         self._hip_decoder = None
+        self._hip_encoder = None
         if self.test_mode:
             self.eval()
             for p in self.parameters(): p.requires_grad_(False)
@@ -55,14 +56,30 @@ class VQVAE(nn.Module):
     def forward(self, inp, ret_usages=False):
         raise NotImplementedError('VQVAE.forward is VAE training (reference vqvae.py:56-59): out of scope of the sampling-path build')
 
-    def img_to_idxBl(self, inp_img_no_grad, v_patch_nums=None) -> List[torch.LongTensor]:
-        return self.quantize.f_to_idxBl_or_fhat(self.quant_conv(self.encoder(inp_img_no_grad)), to_fhat=False, v_patch_nums=v_patch_nums)
-
-    def img_to_fhat(self, inp_img_no_grad, v_patch_nums=None):
-        return self.quantize.f_to_idxBl_or_fhat(self.quant_conv(self.encoder(inp_img_no_grad)), to_fhat=True, v_patch_nums=v_patch_nums)
+    def _encoder_engine(self):
+        if self._hip_encoder is None:
+            from ..engine import EncoderEngine
+            self._hip_encoder = EncoderEngine(self)
+        return self._hip_encoder
 
     def img_to_post(self, inp_img_no_grad, v_patch_nums=None):
-        return self.quant_conv(self.encoder(inp_img_no_grad))
+        """quant_conv(encoder(img)): (B, Cvae, H/16, W/16).  HIP encoder for fp32 CUDA images outside autograd, PyTorch otherwise."""
+        x = inp_img_no_grad
+        if (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and x.shape[-1] % 16 == 0 and x.shape[-2] % 16 == 0
+                and self.quant_conv.kernel_size == (3, 3)):
+            f = self._encoder_engine().encode(x)                         # channels-last (B, h, w, Cvae)
+            from .. import hip
+            B, h, w, C = f.shape
+            out = torch.empty(B, C, h, w, dtype=torch.float32, device=x.device)
+            hip.call('nhwc_to_nchw_f32', f, out, B, C, h * w)
+            return out
+        return self.quant_conv(self.encoder(x))
+
+    def img_to_idxBl(self, inp_img_no_grad, v_patch_nums=None) -> List[torch.LongTensor]:
+        return self.quantize.f_to_idxBl_or_fhat(self.img_to_post(inp_img_no_grad), to_fhat=False, v_patch_nums=v_patch_nums)
+
+    def img_to_fhat(self, inp_img_no_grad, v_patch_nums=None):
+        return self.quantize.f_to_idxBl_or_fhat(self.img_to_post(inp_img_no_grad), to_fhat=True, v_patch_nums=v_patch_nums)
 
     def idxBl_to_img(self, ms_idx_Bl: List[torch.Tensor], same_shape: bool, last_one=False):
         B = ms_idx_Bl[0].shape[0]
@@ -77,7 +94,7 @@ class VQVAE(nn.Module):
         return self.fhat_to_img(f) if last_one else [self.fhat_to_img(x) for x in f]
 
     def img_to_reconstructed_img(self, x, v_patch_nums=None, last_one=False):
-        fs = self.quantize.f_to_idxBl_or_fhat(self.quant_conv(self.encoder(x)), to_fhat=True, v_patch_nums=v_patch_nums)
+        fs = self.quantize.f_to_idxBl_or_fhat(self.img_to_post(x), to_fhat=True, v_patch_nums=v_patch_nums)
         return self.fhat_to_img(fs[-1]) if last_one else [self.fhat_to_img(f) for f in fs]
 
     def load_state_dict(self, state_dict: Dict[str, Any], strict=True, assign=False):
