@@ -212,33 +212,40 @@ int varref_attn_cached_f32(const float* q, const float* kcache, const float* vca
         for (int h = 0; h < H; ++h) {
             const float* K = kcache + ((int64_t)b * H + h) * Lmax * 64;
             const float* Vv = vcache + ((int64_t)b * H + h) * Lmax * 64;
-            float* s = (float*)malloc(sizeof(float) * curL);
+            /* The reference runs flash_attn_func / SDPA here; both are the running-max ("online softmax") recurrence with an
+             * implementation-defined tile.  This restatement fixes the tile at 32 keys:
+             *   m' = max(m, max_tile s); a = exp(m - m'); l = l*a + sum p; O = O*a + sum p v,  p = exp(s - m'),
+             * the row sum kept as two partial sums (even / odd key positions) that are added at the end. */
             for (int t = 0; t < l; ++t) {
                 const float* qr = q + ((int64_t)b * l + t) * C + h * 64;
-                float m = -INFINITY;
-                for (int j = 0; j < curL; ++j) {
-                    float acc = 0.0f;
-                    for (int d = 0; d < 64; ++d) acc = vm_fma(K[(int64_t)j * 64 + d], qr[d], acc);
-                    s[j] = acc; m = vm_max(m, acc);
-                }
-                float le = 0.0f, lo = 0.0f;
-                for (int j = 0; j < curL; ++j) {
-                    s[j] = vm_exp(s[j] - m);
-                    if (j & 1) lo = lo + s[j]; else le = le + s[j];
-                }
-                float lsum = le + lo;
-                float* o = out + ((int64_t)b * l + t) * C + h * 64;
-                float acc[64];
+                float m = -INFINITY, le = 0.0f, lo = 0.0f;
+                float acc[64], s[32];
                 for (int c = 0; c < 64; ++c) acc[c] = 0.0f;
-                for (int j = 0; j < curL; ++j) {
-                    float pj = s[j];
-                    const float* vr = Vv + (int64_t)j * 64;
+                for (int j0 = 0; j0 < curL; j0 += 32) {
+                    const int nj = curL - j0 < 32 ? curL - j0 : 32;
+                    float tmax = -INFINITY;
+                    for (int jj = 0; jj < nj; ++jj) {
+                        float a = 0.0f;
+                        for (int d = 0; d < 64; ++d) a = vm_fma(K[(int64_t)(j0 + jj) * 64 + d], qr[d], a);
+                        s[jj] = a; tmax = vm_max(tmax, a);
+                    }
+                    const float mnew = vm_max(m, tmax);
+                    const float alpha = vm_exp(m - mnew);
+                    m = mnew;
+                    le = le * alpha; lo = lo * alpha;
+                    for (int c = 0; c < 64; ++c) acc[c] = acc[c] * alpha;
+                    for (int jj = 0; jj < nj; ++jj) {
+                        const float pj = vm_exp(s[jj] - m);
+                        if ((j0 + jj) & 1) lo = lo + pj; else le = le + pj;
+                        const float* vr = Vv + (int64_t)(j0 + jj) * 64;
 #pragma omp simd
-                    for (int c = 0; c < 64; ++c) acc[c] = vm_fma(pj, vr[c], acc[c]);
+                        for (int c = 0; c < 64; ++c) acc[c] = vm_fma(pj, vr[c], acc[c]);
+                    }
                 }
+                const float lsum = le + lo;
+                float* o = out + ((int64_t)b * l + t) * C + h * 64;
                 for (int c = 0; c < 64; ++c) o[c] = acc[c] / lsum;
             }
-            free(s);
         }
     }
     return 0;

@@ -5,9 +5,9 @@
 //   - "swapped" scores: S^T = K_tile . Q^T with MFMA 32x32x2 (A = keys, B = queries), so each LANE owns one query
 //     (column) and its 16 accumulator registers are 16 keys: row max / row sum are per-lane register reductions
 //     plus one exchange between the two lane halves.
-//   - two passes over the keys instead of an online softmax: pass 1 finds the exact row max, pass 2 recomputes the
-//     scores (bit-identical), takes p = exp(s - m) and accumulates O^T += V^T . P^T.  No rescaling ever happens,
-//     so the result does not depend on the tile size, and the chain over keys is the natural ascending one.
+//   - one pass over 32-key tiles with a running maximum (flash-attention recurrence): O and the row sum are rescaled by
+//     exp(m_old - m_new) per tile, p = exp(s - m_new), O^T += V^T . P^T along the natural ascending key order.  The
+//     32-key tile is part of the arithmetic contract; the oracle walks the same tiles.
 //   - P feeds the second MFMA straight from the accumulator registers: v_permlane32_swap on register pairs turns the
 //     C-layout (lane half h holds keys 8g+4h+{0..3}) into the B-operand layout (half h holds key 2s+h).
 //   Row-sum order (mirrored by oracle/var_oracle.c): (sum over even keys, ascending) + (sum over odd keys, ascending).
@@ -103,26 +103,14 @@ __global__ void __launch_bounds__(256) k_attn_cached(const float* __restrict__ q
         }
     };
 
-    // ---- pass 1: exact row max
-    float mx = -INFINITY;
-    stage_k(0, 0);
-    __syncthreads();
-    for (int kt = 0; kt < ntile; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < ntile) stage_k(kt + 1, buf ^ 1);
-        f32x16 acc;
-        scores(buf, kt, acc);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) mx = fmaxf(mx, acc[e]);
-        __syncthreads();
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-
-    // ---- pass 2: p = exp(s - m), row sums, O^T += V^T . P^T
+    // ---- one pass over the key tiles with the running maximum (the flash-attention recurrence, tile = 32 keys):
+    //   m' = max(m, max_tile s);  a = exp(m - m');  l = l*a + sum_tile p;  O = O*a + P.V  with p = exp(s - m')
+    // The tile size is part of the arithmetic contract (oracle/var_oracle.c walks the same 32-key tiles), so GPU == oracle bit
+    // for bit; the exact two-pass form this replaced spent a third of its MFMAs recomputing the scores.
     f32x16 o0, o1;
 #pragma unroll
     for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; }
-    float lsum = 0.f;
+    float lsum = 0.f, mx = -INFINITY;
     stage_k(0, 0); stage_v(0, 0);
     __syncthreads();
     for (int kt = 0; kt < ntile; ++kt) {
@@ -130,6 +118,16 @@ __global__ void __launch_bounds__(256) k_attn_cached(const float* __restrict__ q
         if (kt + 1 < ntile) { stage_k(kt + 1, buf ^ 1); stage_v(kt + 1, buf ^ 1); }
         f32x16 p;
         scores(buf, kt, p);
+        float tmax = p[0];
+#pragma unroll
+        for (int e = 1; e < 16; ++e) tmax = fmaxf(tmax, p[e]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));              // both lane halves of a query agree on the tile maximum
+        const float mnew = fmaxf(mx, tmax);
+        const float alpha = vm_exp(mx - mnew);                      // 0 on the first tile (m = -inf), 1 when the maximum stands
+        mx = mnew;
+        lsum = lsum * alpha;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { o0[e] = o0[e] * alpha; o1[e] = o1[e] * alpha; }
 #pragma unroll
         for (int e = 0; e < 16; ++e) p[e] = vm_exp(p[e] - mx);
         swap_pair<0>(p); swap_pair<2>(p); swap_pair<4>(p); swap_pair<6>(p);
