@@ -73,6 +73,15 @@ int varhip_qkv_prep_f32(const float* qkv, const float* scale_mul, float plain_sc
                         float* q_out, float* kcache, float* vcache,
                         int B2, int l, int H, int pos0, int Lmax, varhip_stream_t stream);
 
+/* ---- mat_qkv GEMM with that post-processing fused into its epilogue -------------------------------------
+ * Equivalent, bit for bit, to varhip_gemm_nt_f32(A, W[3C][K], bias[3C]) -> qkv[M][3C] followed by varhip_qkv_prep_f32,
+ * without the [M][3C] round trip through HBM.   replaces basic_var.py:93 (F.linear with the q_bias|zero_k_bias|v_bias
+ * concatenation) through :109.  Requires M == B2*l, C == H*64, K % 32 == 0, lda/ldw % 4 == 0, 16-byte aligned pointers. */
+int varhip_gemm_qkv_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, int M, int C, int K,
+                        const float* scale_mul, float plain_scale, int l2norm,
+                        float* q_out, float* kcache, float* vcache,
+                        int B2, int l, int H, int pos0, int Lmax, varhip_stream_t stream);
+
 /* ---- attention of l new queries over curL cached keys (no mask: block-causal by construction) -----------
  * out[b][t][h*64+c] = sum_j softmax_j(q[b][t][h] . k[b][h][j]) v[b][h][j][c],  j < curL
  * replaces slow_attn / flash_attn_func / memory_efficient_attention at basic_var.py:111-117 (head_dim 64, scale 1:

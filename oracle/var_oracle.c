@@ -201,6 +201,19 @@ int varref_qkv_prep_f32(const float* qkv, const float* scale_mul, float plain_sc
     return 0;
 }
 
+/* mat_qkv + the post-processing above as one call (basic_var.py:93-109): twin of the fused-epilogue HIP entry point,
+ * stated as the two steps it is defined to equal. */
+int varref_gemm_qkv_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, int M, int C, int K,
+                        const float* scale_mul, float plain_scale, int l2norm,
+                        float* q_out, float* kcache, float* vcache, int B2, int l, int H, int pos0, int Lmax) {
+    if (C != H * 64 || M != B2 * l || K <= 0) return VARHIP_EINVAL;
+    float* qkv = (float*)malloc(sizeof(float) * (size_t)M * 3 * C);
+    int rc = varref_gemm_nt_f32(A, lda, W, ldw, bias, qkv, 3 * C, M, 3 * C, K, EPI_NONE, NULL, 0, NULL, 0, 1, 0, 1, 0, 0, 0);
+    if (!rc) rc = varref_qkv_prep_f32(qkv, scale_mul, plain_scale, l2norm, q_out, kcache, vcache, B2, l, H, pos0, Lmax);
+    free(qkv);
+    return rc;
+}
+
 /* slow_attn / SDPA without mask over the cached keys (basic_var.py:111-117).  Row sum of the softmax numerators:
  * (sum over even key positions) + (sum over odd key positions), each ascending — see DESIGN.md §Numerics. */
 int varref_attn_cached_f32(const float* q, const float* kcache, const float* vcache, float* out,

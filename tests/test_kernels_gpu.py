@@ -122,6 +122,21 @@ def test_qkv_prep_exact(B2, l, H, pos0, Lmax, l2):
         check(f'qkv_prep {nm}', g, w)
 
 
+@pytest.mark.parametrize('B2,l,H,K,pos0,Lmax,l2', [(4, 1, 2, 128, 0, 14, 1), (4, 9, 2, 128, 5, 14, 1), (2, 16, 16, 1024, 14, 55, 1), (4, 4, 3, 192, 1, 14, 0),
+                                                   (6, 100, 5, 320, 30, 130, 1), (128, 4, 16, 1024, 1, 5, 1), (3, 169, 1, 64, 0, 169, 1)])
+def test_gemm_qkv_fused_epilogue_exact(B2, l, H, K, pos0, Lmax, l2):
+    """The fused entry point is DEFINED as gemm_nt followed by qkv_prep: same bits, both tile shapes, ragged M, odd H (3C % 128 != 0)."""
+    rng = np.random.default_rng(B2 * l + H + K)
+    C, M = 64 * H, B2 * l
+    A, W, bias = rnd(rng, M, K), rnd(rng, 3 * C, K, scale=0.05), rnd(rng, 3 * C, scale=0.1)
+    sm = (np.log(4.0) + rnd(rng, H, scale=0.5)).astype(np.float32); sm[0] = 6.0
+    q = np.zeros((M, C), np.float32)
+    kc = rnd(rng, B2, H, Lmax, 64); vc = rnd(rng, B2, H, Lmax, 64)
+    outs_h, outs_r = both('gemm_qkv_f32', [A, K, W, K, bias, M, C, K, sm if l2 else None, 0.03125, l2, q, kc, vc, B2, l, H, pos0, Lmax], [11, 12, 13])
+    for nm, g, w in zip(('q', 'kcache', 'vcache'), outs_h, outs_r):
+        check(f'gemm_qkv {nm}', g, w)
+
+
 @pytest.mark.parametrize('B2,l,H,curL,Lmax', [(4, 1, 2, 1, 14), (4, 4, 2, 5, 14), (4, 9, 2, 14, 14), (2, 25, 2, 55, 55), (2, 100, 3, 255, 300), (2, 256, 2, 680, 680), (1, 169, 1, 424, 680)])
 def test_attn_cached_exact(B2, l, H, curL, Lmax):
     rng = np.random.default_rng(l * 3 + curL)

@@ -21,6 +21,8 @@ struct GemmP {
     int H, Wd, Cin, up2, out_mode, Hi, Wi;     // convolution only
     int tilesM, tilesN;
     int evec;                                   // epilogue may use 16-byte accesses (N, leading dims and pointers allow it)
+    // epi == 3 (fused q/k/v epilogue, varhip_gemm_qkv_f32): N = 3C, head_dim 64
+    const float* q_smul; float* q_out; float* q_kc; float* q_vc; float q_plain; int q_l2, q_l, q_pos0, q_Lmax;
 };
 
 template <int TM, int TN, int WGM, int WGN, int BK, bool CONV, bool VEC>
@@ -200,6 +202,60 @@ __global__ void __launch_bounds__(256) k_mfma_gemm(GemmP p) {
     // lane per row.  Each wave transposes one accumulator at a time through a private LDS patch (the K-loop stages are
     // free now: the loop ended on a barrier) so that a lane owns 4 consecutive columns of a row: bias / gamma / residual
     // are read and the result is written with 16-byte accesses, 4x fewer memory instructions than the direct layout.
+    if constexpr (!CONV && TN == 2) {
+        if (p.epi == 3) {
+            // ---- fused q/k/v post-processing (SelfAttention.forward up to the cache append, basic_var.py:98-109): a wave's two
+            // column tiles are exactly one 64-wide head of q, k or v.  Both accumulators of a row tile go through LDS together so a
+            // lane owns 4 consecutive channels of a (row, head); the sum of squares follows the canonical W64 butterfly of k_qkv_prep
+            // (element i = channel within the head; offsets 32,16,8,4 cross lanes, 2 and 1 are inside the lane's float4).
+            constexpr int EPQ = 68;
+            float* epq = smem + wave * (32 * EPQ);
+            const int col0 = n0 + wn * 64, C = p.N / 3;
+            if (col0 >= p.N) return;
+            const int sect = col0 / C, head = (col0 - sect * C) >> 6, Hh = C >> 6;
+            const int c4 = (lane & 15) * 4;
+            const f32x4 b4 = p.bias ? *(const f32x4*)(p.bias + col0 + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const float sm = (p.q_l2 && sect == 0) ? vm_exp(vm_min(p.q_smul[head], 4.605170249938965f)) : 1.0f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int tm0 = m0 + (wm * TM + i) * 32;
+                if (tm0 >= p.M) continue;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) epq[((e & 3) + 8 * (e >> 2) + 4 * h) * EPQ + j * 32 + r] = acc[i][j][e];
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int row = it * 4 + (lane >> 4), m = tm0 + row;
+                    f32x4 v = *(const f32x4*)(epq + row * EPQ + c4);
+                    v[0] = v[0] + b4[0]; v[1] = v[1] + b4[1]; v[2] = v[2] + b4[2]; v[3] = v[3] + b4[3];
+                    if (p.q_l2 && sect < 2) {
+                        float s0 = v[0] * v[0], s1 = v[1] * v[1], s2 = v[2] * v[2], s3 = v[3] * v[3];
+#pragma unroll
+                        for (int off = 8; off >= 1; off >>= 1) {            // element offsets 32,16,8,4 == lane offsets 8,4,2,1
+                            s0 = s0 + __shfl_xor(s0, off, 64); s1 = s1 + __shfl_xor(s1, off, 64);
+                            s2 = s2 + __shfl_xor(s2, off, 64); s3 = s3 + __shfl_xor(s3, off, 64);
+                        }
+                        const float t0 = s0 + s2, t1 = s1 + s3;              // element offset 2
+                        const float ss = t0 + t1;                            // element offset 1
+                        const float den = vm_max(vm_sqrt(ss), 1e-12f);
+                        if (sect == 0) { v[0] = (v[0] / den) * sm; v[1] = (v[1] / den) * sm; v[2] = (v[2] / den) * sm; v[3] = (v[3] / den) * sm; }
+                        else { v[0] = v[0] / den; v[1] = v[1] / den; v[2] = v[2] / den; v[3] = v[3] / den; }
+                    } else if (!p.q_l2 && sect == 0) {
+                        v[0] = v[0] * p.q_plain; v[1] = v[1] * p.q_plain; v[2] = v[2] * p.q_plain; v[3] = v[3] * p.q_plain;
+                    }
+                    if (m >= p.M) continue;
+                    if (sect == 0) *(f32x4*)(p.q_out + (int64_t)m * C + head * 64 + c4) = v;
+                    else {
+                        const int bb = m / p.q_l, t = m - bb * p.q_l;
+                        float* dst = (sect == 1 ? p.q_kc : p.q_vc) + (((int64_t)bb * Hh + head) * p.q_Lmax + p.q_pos0 + t) * 64 + c4;
+                        *(f32x4*)dst = v;
+                    }
+                }
+            }
+            return;
+        }
+    }
     constexpr int EPW = 36;
     float* ep = smem + wave * (32 * EPW);
 #pragma unroll
@@ -319,6 +375,30 @@ extern "C" int varhip_gemm_nt_f32(const float* A, int64_t lda, const float* W, i
         case 2: return launch_gemm<1, 1, 2, 2, 32, false>(p, batch, (hipStream_t)stream);
         default: return launch_gemm<1, 1, 2, 2, 32, false, false>(p, batch, (hipStream_t)stream);
     }
+}
+
+// ---- mat_qkv with the q/k/v post-processing in the epilogue (basic_var.py:93-109): the [M][3C] intermediate never reaches HBM.
+// Arithmetic identical to varhip_gemm_nt_f32 followed by varhip_qkv_prep_f32 (same fma chains, same W64 butterfly).
+extern "C" int varhip_gemm_qkv_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, int M, int C, int K,
+                                   const float* scale_mul, float plain_scale, int l2norm,
+                                   float* q_out, float* kcache, float* vcache, int B2, int l, int H, int pos0, int Lmax,
+                                   varhip_stream_t stream) {
+    if (B2 <= 0 || l <= 0 || H <= 0 || pos0 < 0 || pos0 + l > Lmax || (l2norm && !scale_mul)) return VARHIP_EINVAL;
+    if (C != H * 64 || M != B2 * l || K <= 0 || (K & 31) || (lda & 3) || (ldw & 3)) return VARHIP_EINVAL;
+    if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)bias | (uintptr_t)q_out | (uintptr_t)kcache | (uintptr_t)vcache) & 15)) return VARHIP_EINVAL;
+    GemmP p{};
+    p.A = A; p.W = W; p.bias = bias; p.lda = lda; p.ldw = ldw;
+    p.M = M; p.N = 3 * C; p.K = K; p.epi = 3; p.rows_per_group = 1;
+    p.q_smul = scale_mul; p.q_out = q_out; p.q_kc = kcache; p.q_vc = vcache; p.q_plain = plain_scale;
+    p.q_l2 = l2norm; p.q_l = l; p.q_pos0 = pos0; p.q_Lmax = Lmax;
+    auto cost = [&](int bm, double eff) {
+        const int64_t nb = (int64_t)((M + bm - 1) / bm) * ((3 * C + 127) / 128);
+        return (double)((nb + 255) / 256) * bm / eff;
+    };
+    const bool big = cost(128, 1.0) <= cost(64, 0.9);
+    VhScope scope(big ? VH_FAM_GEMM : VH_FAM_GEMM_SMALL, (hipStream_t)stream, 2.0 * M * 3.0 * C * (double)K,
+                  4.0 * ((double)M * K + 3.0 * C * K + 3.0 * M * C));
+    return big ? launch_gemm<2, 2, 2, 2, 32, false>(p, 1, (hipStream_t)stream) : launch_gemm<1, 2, 2, 2, 32, false>(p, 1, (hipStream_t)stream);
 }
 
 extern "C" int varhip_conv3x3_nhwc_f32(const float* in, const float* w, const float* bias, const float* resid, float* out,

@@ -394,7 +394,7 @@ class SamplingEngine:
         M = 2 * B * lmax
         hid = var.blocks[0].ffn.fc1.weight.shape[0]
         e = lambda *s, dt=torch.float32: torch.empty(*s, dtype=dt, device=dev)
-        ws = dict(dev=dev, x=e(M, C), x2=e(M, C), xn=e(M, C), qkv=e(M, 3 * C), q=e(M, C), att=e(M, C), hid=e(M, hid), logits=e(M, V),
+        ws = dict(dev=dev, x=e(M, C), x2=e(M, C), xn=e(M, C), q=e(M, C), att=e(M, C), hid=e(M, hid), logits=e(M, V),
                   idx=e(B * lmax, dt=torch.int64), lvl_pos=e(L, C), cond=e(2 * B, C), cond_silu=e(2 * B, C), hn=e(2 * B, 2 * C),
                   ada=e(var.depth, 2 * B, 6 * C), shared=e(2 * B, 6 * C) if var.shared_aln else None,
                   kc=[torch.zeros(2 * B, H, L, 64, dtype=torch.float32, device=dev) for _ in range(var.depth)],
@@ -406,6 +406,12 @@ class SamplingEngine:
     def gemm(self, A, W, bias, out, M, epi=EPI_NONE, resid=None, gamma=None, ldg=0, rpg=1):
         N, K = W.shape
         hip.call('gemm_nt_f32', A, K, W, K, bias, out, N, M, N, K, epi, resid, N, gamma, ldg, rpg, 0, 1, 0, 0, 0)
+
+    def qkv(self, xn, blk, ws, bi, rows, l, cur):
+        """mat_qkv + q/k normalisation + KV-cache append in one launch (basic_var.py:93-109)."""
+        C, H = self.var.C, self.var.num_heads
+        hip.call('gemm_qkv_f32', xn, C, blk['qkv_w'], C, blk['qkv_b'], rows * l, C, C, blk['smul'], blk['plain_scale'], int(blk['l2']),
+                 ws['q'], ws['kc'][bi], ws['vc'][bi], rows, l, H, cur, self.var.L)
 
     # -- the loop ----------------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -476,9 +482,7 @@ class SamplingEngine:
                 ada = ws['ada'][bi]
                 g1, g2, s1, s2, h1, h2 = (ada[:, i * C:] for i in range(6))       # interior pointers, row stride 6C
                 hip.call('ln_modulate_f32', x, s1, 6 * C, h1, 6 * C, ws['xn'], M, C, l, var.norm_eps)
-                self.gemm(ws['xn'], blk['qkv_w'], blk['qkv_b'], ws['qkv'], M)
-                hip.call('qkv_prep_f32', ws['qkv'], blk['smul'], blk['plain_scale'], int(blk['l2']), ws['q'], ws['kc'][bi], ws['vc'][bi],
-                         B2, l, H, cur, var.L)
+                self.qkv(ws['xn'], blk, ws, bi, B2, l, cur)
                 hip.call('attn_cached_f32', ws['q'], ws['kc'][bi], ws['vc'][bi], ws['att'], B2, l, H, cur + l, var.L)
                 self.gemm(ws['att'], blk['proj_w'], blk['proj_b'], x2, M, EPI_RESID, resid=x, gamma=g1, ldg=6 * C, rpg=l)
                 hip.call('ln_modulate_f32', x2, s2, 6 * C, h2, 6 * C, ws['xn'], M, C, l, var.norm_eps)
@@ -557,7 +561,7 @@ class SamplingEngine:
             e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
             M = R * lmax
             # x is written by first_map_f32 / word_embed_f32, which also emit the CFG copy of every row (unused here): room for 2x
-            ws = dict(dev=dev, x=e(2 * M, C), x2=e(M, C), xn=e(M, C), qkv=e(M, 3 * C), q=e(M, C), att=e(M, C), hid=e(M, hid), lg=e(R * lmax, V),
+            ws = dict(dev=dev, x=e(2 * M, C), x2=e(M, C), xn=e(M, C), q=e(M, C), att=e(M, C), hid=e(M, hid), lg=e(R * lmax, V),
                       lvl_pos=e(L, C), cond=e(2 * R, C), cond_silu=e(2 * R, C), hn=e(R, 2 * C), ada=e(var.depth, R, 6 * C),
                       shared=e(R, 6 * C) if var.shared_aln else None,
                       kc=[torch.zeros(R, H, L, 64, dtype=torch.float32, device=dev) for _ in range(var.depth)],
@@ -589,8 +593,7 @@ class SamplingEngine:
                 ada = ws['ada'][bi]
                 g1, g2, s1, s2, h1, h2 = (ada[:, i * C:] for i in range(6))
                 hip.call('ln_modulate_f32', x, s1, 6 * C, h1, 6 * C, ws['xn'], M, C, l, var.norm_eps)
-                self.gemm(ws['xn'], blk['qkv_w'], blk['qkv_b'], ws['qkv'], M)
-                hip.call('qkv_prep_f32', ws['qkv'], blk['smul'], blk['plain_scale'], int(blk['l2']), ws['q'], ws['kc'][bi], ws['vc'][bi], R, l, H, cur, L)
+                self.qkv(ws['xn'], blk, ws, bi, R, l, cur)
                 hip.call('attn_cached_f32', ws['q'], ws['kc'][bi], ws['vc'][bi], ws['att'], R, l, H, cur + l, L)
                 self.gemm(ws['att'], blk['proj_w'], blk['proj_b'], x2, M, EPI_RESID, resid=x, gamma=g1, ldg=6 * C, rpg=l)
                 hip.call('ln_modulate_f32', x2, s2, 6 * C, h2, 6 * C, ws['xn'], M, C, l, var.norm_eps)
