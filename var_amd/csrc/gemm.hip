@@ -202,60 +202,6 @@ __global__ void __launch_bounds__(256) k_mfma_gemm(GemmP p) {
     // lane per row.  Each wave transposes one accumulator at a time through a private LDS patch (the K-loop stages are
     // free now: the loop ended on a barrier) so that a lane owns 4 consecutive columns of a row: bias / gamma / residual
     // are read and the result is written with 16-byte accesses, 4x fewer memory instructions than the direct layout.
-    if constexpr (!CONV && TN == 2) {
-        if (p.epi == 3) {
-            // ---- fused q/k/v post-processing (SelfAttention.forward up to the cache append, basic_var.py:98-109): a wave's two
-            // column tiles are exactly one 64-wide head of q, k or v.  Both accumulators of a row tile go through LDS together so a
-            // lane owns 4 consecutive channels of a (row, head); the sum of squares follows the canonical W64 butterfly of k_qkv_prep
-            // (element i = channel within the head; offsets 32,16,8,4 cross lanes, 2 and 1 are inside the lane's float4).
-            constexpr int EPQ = 68;
-            float* epq = smem + wave * (32 * EPQ);
-            const int col0 = n0 + wn * 64, C = p.N / 3;
-            if (col0 >= p.N) return;
-            const int sect = col0 / C, head = (col0 - sect * C) >> 6, Hh = C >> 6;
-            const int c4 = (lane & 15) * 4;
-            const f32x4 b4 = p.bias ? *(const f32x4*)(p.bias + col0 + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
-            const float sm = (p.q_l2 && sect == 0) ? vm_exp(vm_min(p.q_smul[head], 4.605170249938965f)) : 1.0f;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int tm0 = m0 + (wm * TM + i) * 32;
-                if (tm0 >= p.M) continue;
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) epq[((e & 3) + 8 * (e >> 2) + 4 * h) * EPQ + j * 32 + r] = acc[i][j][e];
-#pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    const int row = it * 4 + (lane >> 4), m = tm0 + row;
-                    f32x4 v = *(const f32x4*)(epq + row * EPQ + c4);
-                    v[0] = v[0] + b4[0]; v[1] = v[1] + b4[1]; v[2] = v[2] + b4[2]; v[3] = v[3] + b4[3];
-                    if (p.q_l2 && sect < 2) {
-                        float s0 = v[0] * v[0], s1 = v[1] * v[1], s2 = v[2] * v[2], s3 = v[3] * v[3];
-#pragma unroll
-                        for (int off = 8; off >= 1; off >>= 1) {            // element offsets 32,16,8,4 == lane offsets 8,4,2,1
-                            s0 = s0 + __shfl_xor(s0, off, 64); s1 = s1 + __shfl_xor(s1, off, 64);
-                            s2 = s2 + __shfl_xor(s2, off, 64); s3 = s3 + __shfl_xor(s3, off, 64);
-                        }
-                        const float t0 = s0 + s2, t1 = s1 + s3;              // element offset 2
-                        const float ss = t0 + t1;                            // element offset 1
-                        const float den = vm_max(vm_sqrt(ss), 1e-12f);
-                        if (sect == 0) { v[0] = (v[0] / den) * sm; v[1] = (v[1] / den) * sm; v[2] = (v[2] / den) * sm; v[3] = (v[3] / den) * sm; }
-                        else { v[0] = v[0] / den; v[1] = v[1] / den; v[2] = v[2] / den; v[3] = v[3] / den; }
-                    } else if (!p.q_l2 && sect == 0) {
-                        v[0] = v[0] * p.q_plain; v[1] = v[1] * p.q_plain; v[2] = v[2] * p.q_plain; v[3] = v[3] * p.q_plain;
-                    }
-                    if (m >= p.M) continue;
-                    if (sect == 0) *(f32x4*)(p.q_out + (int64_t)m * C + head * 64 + c4) = v;
-                    else {
-                        const int bb = m / p.q_l, t = m - bb * p.q_l;
-                        float* dst = (sect == 1 ? p.q_kc : p.q_vc) + (((int64_t)bb * Hh + head) * p.q_Lmax + p.q_pos0 + t) * 64 + c4;
-                        *(f32x4*)dst = v;
-                    }
-                }
-            }
-            return;
-        }
-    }
     constexpr int EPW = 36;
     float* ep = smem + wave * (32 * EPW);
 #pragma unroll
@@ -328,6 +274,246 @@ __global__ void __launch_bounds__(256) k_mfma_gemm(GemmP p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// k_dma_gemm — the dense GEMM of the transformer (K % 32 == 0, 16-byte aligned operands): same arithmetic contract, leaner
+// data path.  Both operand tiles go global -> LDS with the LDS-DMA instruction (global_load_lds, 16 B per lane): no staging
+// VGPRs, no ds_write.  One instruction moves 8 rows x 128 B; a lane cannot choose its LDS slot (slot = lane), so the
+// bank-conflict swizzle is applied on the SOURCE side: slot c of row r receives 16-byte chunk c ^ (r & 7), and the reader
+// of k-step s looks in slot s ^ (r & 7).
+// MFMA 16x16x4 (4 k per instruction, k = lane >> 4 -> one ds_read_b32 per operand tile per step, natural k order, the
+// same k-ascending fma chain per output as the 32x32x2 form).  The WEIGHT tile is the A operand, so D[row = n][col = m]:
+// a lane ends up with 4 consecutive n of one m and the epilogue (bias / GELU / gamma / residual / q-k-v prep) runs on float4s
+// straight from the accumulators, no LDS transpose.
+// 2x2 waves; a wave owns (TMW*16) x (TNW*16) outputs.  Two LDS stages, one barrier per K tile.
+__device__ __attribute__((aligned(128))) float g_zero_row[32];      // source of the zero padding taps of the convolution (never written)
+
+template <int TMW, int TNW, bool CONV>
+__global__ void __launch_bounds__(256) k_dma_gemm(GemmP p) {
+    constexpr int BK = 32, BM = TMW * 32, BN = TNW * 32, STAGE = (BM + BN) * BK;
+    constexpr int NIA = BM / 32, NIB = BN / 32;                   // DMA instructions per wave and K tile
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int tm_, tn_;
+    {
+        const int nwg = p.tilesM * p.tilesN, bid = blockIdx.x;
+        const int q = nwg >> 3, rem = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        const int lin = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + loc;
+        const int GM = 8, width = GM * p.tilesN, group = lin / width, first = group * GM;
+        const int gsz = (p.tilesM - first) < GM ? (p.tilesM - first) : GM;
+        tm_ = first + (lin % width) % gsz;
+        tn_ = (lin % width) / gsz;
+    }
+    const int m0 = tm_ * BM, n0 = tn_ * BN;
+    const int bz = blockIdx.z;
+    const float* Ab = p.A + (int64_t)bz * p.sA;
+    const float* Wb = p.W + (int64_t)bz * p.sW;
+    float* Ob = p.out + (int64_t)bz * p.sO;
+
+    // DMA roles: wave w stages rows [w*BM/4, (w+1)*BM/4) of the activation tile and [w*BN/4, ...) of the weight tile.
+    // Rows past M / N are clamped to the last valid row: they only feed outputs that are never stored.
+    const int drow = lane >> 3, dslot = lane & 7;
+    const float* asrc[NIA]; const float* bsrc[NIB];
+    int a_b[NIA], a_y[NIA], a_x[NIA];                             // CONV: pixel of the row
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) {
+        int m = m0 + wave * (BM / 4) + i * 8 + drow; m = m < p.M ? m : p.M - 1;
+        if (CONV) {
+            const int hw = p.H * p.Wd;
+            a_b[i] = m / hw; const int rem2 = m - a_b[i] * hw; a_y[i] = rem2 / p.Wd; a_x[i] = rem2 - a_y[i] * p.Wd;
+            asrc[i] = Ab + ((dslot ^ drow) << 2);
+        } else {
+            asrc[i] = Ab + (int64_t)m * p.lda + ((dslot ^ drow) << 2);
+        }
+    }
+    const float* zsrc = g_zero_row + ((dslot ^ drow) << 2);
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) {
+        int n = n0 + wave * (BN / 4) + i * 8 + drow; n = n < p.N ? n : p.N - 1;
+        bsrc[i] = Wb + (int64_t)n * p.ldw + ((dslot ^ drow) << 2);
+    }
+    auto dma_tile = [&](int kt, int st) {
+        float* sA = smem + st * STAGE + wave * (BM / 4) * BK;
+        float* sB = smem + st * STAGE + BM * BK + wave * (BN / 4) * BK;
+        int dy = 0, dx = 0, ci0 = 0;
+        if (CONV) {                                               // K index = tap * Cin + ci: the tile lies inside one tap (Cin % 32 == 0)
+            const int k0 = kt * BK, tap = k0 / p.Cin;
+            ci0 = k0 - tap * p.Cin;
+            if (p.up2 == 2) { dy = (tap >> 1) - 1 + (bz >> 1); dx = (tap & 1) - 1 + (bz & 1); }   // phase (bz>>1, bz&1) of the folded Upsample2x conv
+            else { const int ky = tap / 3; dy = ky - (p.up2 == 3 ? 0 : 1); dx = tap - ky * 3 - (p.up2 == 3 ? 0 : 1); }
+        }
+#pragma unroll
+        for (int i = 0; i < NIA; ++i) {
+            const float* src;
+            if (CONV) {
+                // up2: 0 plain, 1 nearest-2x gather, 2 phase conv on the low-res map, 3 stride 2 over an input zero-padded at the bottom/right
+                const int yy = (p.up2 == 3 ? 2 * a_y[i] : a_y[i]) + dy, xx = (p.up2 == 3 ? 2 * a_x[i] : a_x[i]) + dx;
+                const bool ok = yy >= 0 && xx >= 0 && (p.up2 == 3 ? (yy < p.Hi && xx < p.Wi) : (yy < p.H && xx < p.Wd));
+                const int sy = p.up2 == 1 ? (yy >> 1) : yy, sx = p.up2 == 1 ? (xx >> 1) : xx;
+                src = ok ? asrc[i] + (((int64_t)a_b[i] * p.Hi + sy) * p.Wi + sx) * p.Cin + ci0 : zsrc;
+            } else {
+                src = asrc[i] + kt * BK;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(sA + i * 8 * BK), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NIB; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[i] + kt * BK),
+                                             (__attribute__((address_space(3))) void*)(sB + i * 8 * BK), 16, 0, 0);
+    };
+
+    f32x4 acc[TMW][TNW];
+#pragma unroll
+    for (int i = 0; i < TMW; ++i)
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int nk = p.K / BK;
+    dma_tile(0, 0);
+    __syncthreads();                                              // includes the wait for this wave's own DMA (vmcnt)
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) dma_tile(kt + 1, cur ^ 1);               // stage cur^1 was last read before the previous barrier
+        const float* sA = smem + cur * STAGE + (wm * TMW * 16 + r16) * BK + kq;
+        const float* sB = smem + cur * STAGE + BM * BK + (wn * TNW * 16 + r16) * BK + kq;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int sl = (s ^ (r16 & 7)) << 2;                  // rows i*16 + r16: (row & 7) == (r16 & 7)
+            float am[TMW], bn[TNW];
+#pragma unroll
+            for (int i = 0; i < TMW; ++i) am[i] = sA[i * 16 * BK + sl];
+#pragma unroll
+            for (int j = 0; j < TNW; ++j) bn[j] = sB[j * 16 * BK + sl];
+#pragma unroll
+            for (int i = 0; i < TMW; ++i)
+#pragma unroll
+                for (int j = 0; j < TNW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bn[j], am[i], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: acc[i][j][e] = C[m = tile_m(i) + r16][n = tile_n(j) + 4*kq + e]
+    const int nw0 = n0 + wn * TNW * 16;
+    if (nw0 >= p.N) return;
+    if constexpr (!CONV && TNW == 4) {
+        if (p.epi == 3) {
+            // fused q/k/v post-processing (SelfAttention.forward up to the cache append, basic_var.py:98-109): the wave's 64 columns
+            // are one head of q, k or v.  Sum of squares in the canonical W64 butterfly order of k_qkv_prep with element c = channel =
+            // 16j + 4kq + e: offsets 32,16 pair the j tiles (registers), 8,4 pair kq (lanes ^32, ^16), 2,1 pair e (registers).
+            const int C = p.N / 3, sect = nw0 / C, head = (nw0 - sect * C) >> 6, Hh = C >> 6;
+            f32x4 b4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b4[j] = p.bias ? *(const f32x4*)(p.bias + nw0 + j * 16 + kq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const float sm = (p.q_l2 && sect == 0) ? vm_exp(vm_min(p.q_smul[head], 4.605170249938965f)) : 1.0f;
+#pragma unroll
+            for (int i = 0; i < TMW; ++i) {
+                const int m = m0 + (wm * TMW + i) * 16 + r16;
+                f32x4 v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[i][j] + b4[j];
+                if (p.q_l2 && sect < 2) {
+                    const f32x4 a0 = v[0] * v[0] + v[2] * v[2], a1 = v[1] * v[1] + v[3] * v[3];     // offset 32
+                    f32x4 b = a0 + a1;                                                               // offset 16
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) b[e] = b[e] + __shfl_xor(b[e], 32, 64);              // offset 8
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) b[e] = b[e] + __shfl_xor(b[e], 16, 64);              // offset 4
+                    const float t0 = b[0] + b[2], t1 = b[1] + b[3];                                  // offset 2
+                    const float den = vm_max(vm_sqrt(t0 + t1), 1e-12f);                              // offset 1
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[j][e] = sect == 0 ? (v[j][e] / den) * sm : v[j][e] / den;
+                } else if (!p.q_l2 && sect == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = v[j] * p.q_plain;
+                }
+                if (m >= p.M) continue;
+                float* dst;
+                if (sect == 0) dst = p.q_out + (int64_t)m * C + head * 64;
+                else {
+                    const int bb = m / p.q_l, t = m - bb * p.q_l;
+                    dst = (sect == 1 ? p.q_kc : p.q_vc) + (((int64_t)bb * Hh + head) * p.q_Lmax + p.q_pos0 + t) * 64;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) *(f32x4*)(dst + j * 16 + kq * 4) = v[j];
+            }
+            return;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < TNW; ++j) {
+        const int n = nw0 + j * 16 + kq * 4;
+        if (n >= p.N) continue;
+        const bool full = p.evec && (n + 3 < p.N);
+        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && !p.bias_per_row) {
+            if (full) b4 = *(const f32x4*)(p.bias + n);
+            else { for (int e = 0; e < 4; ++e) if (n + e < p.N) b4[e] = p.bias[n + e]; }
+        }
+#pragma unroll
+        for (int i = 0; i < TMW; ++i) {
+            const int m = m0 + (wm * TMW + i) * 16 + r16;
+            if (m >= p.M) continue;
+            f32x4 v = acc[i][j];
+            int64_t mo = m;                                                 // output row; phase mode scatters to the 2x grid
+            if (CONV) {
+                const int hw = p.H * p.Wd, b = m / hw, rem2 = m - b * hw;
+                if (p.out_mode != 0) {                                      // last conv: NCHW store of <= 3 channels, clamp (+ de-normalise)
+                    for (int e = 0; e < 4; ++e) {
+                        if (n + e >= p.N) break;
+                        const float x = vm_min(vm_max(v[e] + b4[e], -1.0f), 1.0f);
+                        Ob[((int64_t)b * p.N + n + e) * hw + rem2] = p.out_mode == 1 ? (x + 1.0f) * 0.5f : x;
+                    }
+                    continue;
+                }
+                if (p.up2 == 2) {
+                    const int y = rem2 / p.Wd, x = rem2 - y * p.Wd;
+                    mo = ((int64_t)b * (2 * p.H) + 2 * y + (bz >> 1)) * (2 * p.Wd) + 2 * x + (bz & 1);
+                }
+            }
+            if (p.bias) { if (p.bias_per_row) { const float bm = p.bias[m]; v[0] = v[0] + bm; v[1] = v[1] + bm; v[2] = v[2] + bm; v[3] = v[3] + bm; }
+                          else v = v + b4; }
+            if (p.epi == VARHIP_EPI_GELU) { v[0] = vm_gelu_tanh(v[0]); v[1] = vm_gelu_tanh(v[1]); v[2] = vm_gelu_tanh(v[2]); v[3] = vm_gelu_tanh(v[3]); }
+            if (full) {
+                if (p.epi == VARHIP_EPI_RESID) {
+                    if (p.gamma) v = v * *(const f32x4*)(p.gamma + (int64_t)(m / p.rows_per_group) * p.ldg + n);
+                    v = *(const f32x4*)(p.resid + (int64_t)m * p.ldr + n) + v;
+                }
+                *(f32x4*)(Ob + mo * p.ldo + n) = v;
+            } else {
+                for (int e = 0; e < 4; ++e) {
+                    if (n + e >= p.N) break;
+                    float x = v[e];
+                    if (p.epi == VARHIP_EPI_RESID) {
+                        if (p.gamma) x = x * p.gamma[(int64_t)(m / p.rows_per_group) * p.ldg + n + e];
+                        x = p.resid[(int64_t)m * p.ldr + n + e] + x;
+                    }
+                    Ob[mo * p.ldo + n + e] = x;
+                }
+            }
+        }
+    }
+}
+
+template <int TMW, int TNW, bool CONV = false>
+static int launch_dma(GemmP& p, int batch, hipStream_t stream) {
+    constexpr int BM = TMW * 32, BN = TNW * 32;
+    constexpr size_t lds = 2 * (size_t)(BM + BN) * 32 * sizeof(float);
+    p.tilesM = (p.M + BM - 1) / BM; p.tilesN = (p.N + BN - 1) / BN;
+    auto kfn = k_dma_gemm<TMW, TNW, CONV>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    dim3 grid(p.tilesM * p.tilesN, 1, batch);
+    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, stream, p);
+    return vh_launch_status();
+}
+
 template <int TM, int TN, int WGM, int WGN, int BK, bool CONV, bool VEC = true>
 static int launch_gemm(GemmP& p, int batch, hipStream_t stream) {
     constexpr int BM = TM * 32 * WGM, BN = TN * 32 * WGN;
@@ -365,16 +551,30 @@ extern "C" int varhip_gemm_nt_f32(const float* A, int64_t lda, const float* W, i
         const int64_t nb = (int64_t)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch;
         return (double)((nb + 255) / 256) * bm * bn / eff;
     };
-    const double c128 = cost(128, 128, 1.0), c12864 = cost(128, 64, 0.93), c64 = cost(64, 64, 0.78);
+    const double c128 = cost(128, 128, 1.0), c12864 = cost(128, 64, 0.97), c64 = cost(64, 64, 0.93);
     const int pick = !vec ? 3 : (c128 <= c12864 && c128 <= c64) ? 0 : (c12864 <= c64 ? 1 : 2);
     VhScope scope(pick == 0 ? VH_FAM_GEMM : VH_FAM_GEMM_SMALL, (hipStream_t)stream, 2.0 * M * N * (double)K * batch,
                   4.0 * batch * ((double)M * K + (double)N * K + (double)M * N));
     switch (pick) {
-        case 0: return launch_gemm<2, 2, 2, 2, 32, false>(p, batch, (hipStream_t)stream);
-        case 1: return launch_gemm<2, 1, 2, 2, 32, false>(p, batch, (hipStream_t)stream);
-        case 2: return launch_gemm<1, 1, 2, 2, 32, false>(p, batch, (hipStream_t)stream);
-        default: return launch_gemm<1, 1, 2, 2, 32, false, false>(p, batch, (hipStream_t)stream);
+        case 0: return launch_dma<4, 4>(p, batch, (hipStream_t)stream);
+        case 1: return launch_dma<4, 2>(p, batch, (hipStream_t)stream);
+        case 2: return launch_dma<2, 2>(p, batch, (hipStream_t)stream);
+        default: return launch_gemm<1, 1, 2, 2, 32, false, false>(p, batch, (hipStream_t)stream);   // any K / alignment: element-wise loads
     }
+}
+
+// tile choice of the implicit-GEMM convolutions: the N tile divides Cout (160/320/640 -> 160 wide)
+static int launch_conv(GemmP& p, int batch, hipStream_t s) {
+    if ((p.Cin & 31) == 0) {                   // LDS-DMA kernel: a K tile of 32 lies inside one tap
+        if (p.N % 160 == 0) return launch_dma<4, 5, true>(p, batch, s);
+        if (p.N % 128 == 0) return launch_dma<4, 4, true>(p, batch, s);
+        if (p.N % 64 == 0) return launch_dma<4, 2, true>(p, batch, s);
+        return launch_dma<4, 1, true>(p, batch, s);
+    }
+    if (p.N % 160 == 0) return launch_gemm<1, 5, 4, 1, 16, true>(p, batch, s);
+    if (p.N % 128 == 0) return launch_gemm<1, 4, 4, 1, 16, true>(p, batch, s);
+    if (p.N % 64 == 0) return launch_gemm<1, 2, 4, 1, 16, true>(p, batch, s);
+    return launch_gemm<1, 1, 4, 1, 16, true>(p, batch, s);
 }
 
 // ---- mat_qkv with the q/k/v post-processing in the epilogue (basic_var.py:93-109): the [M][3C] intermediate never reaches HBM.
@@ -395,10 +595,10 @@ extern "C" int varhip_gemm_qkv_f32(const float* A, int64_t lda, const float* W, 
         const int64_t nb = (int64_t)((M + bm - 1) / bm) * ((3 * C + 127) / 128);
         return (double)((nb + 255) / 256) * bm / eff;
     };
-    const bool big = cost(128, 1.0) <= cost(64, 0.9);
+    const bool big = cost(128, 1.0) <= cost(64, 0.97);
     VhScope scope(big ? VH_FAM_GEMM : VH_FAM_GEMM_SMALL, (hipStream_t)stream, 2.0 * M * 3.0 * C * (double)K,
                   4.0 * ((double)M * K + 3.0 * C * K + 3.0 * M * C));
-    return big ? launch_gemm<2, 2, 2, 2, 32, false>(p, 1, (hipStream_t)stream) : launch_gemm<1, 2, 2, 2, 32, false>(p, 1, (hipStream_t)stream);
+    return big ? launch_dma<4, 4>(p, 1, (hipStream_t)stream) : launch_dma<2, 4>(p, 1, (hipStream_t)stream);
 }
 
 extern "C" int varhip_conv3x3_nhwc_f32(const float* in, const float* w, const float* bias, const float* resid, float* out,
@@ -417,10 +617,7 @@ extern "C" int varhip_conv3x3_nhwc_f32(const float* in, const float* w, const fl
     VhScope scope(VH_FAM_CONV, (hipStream_t)stream, 2.0 * npix * Cout * 9.0 * Cin,
                   4.0 * (npix * Cin / (up2 ? 4.0 : 1.0) + npix * Cout * (resid ? 2.0 : 1.0) + 9.0 * Cin * Cout));
     hipStream_t s = (hipStream_t)stream;
-    if (Cout % 160 == 0) return launch_gemm<1, 5, 4, 1, 16, true>(p, 1, s);
-    if (Cout % 128 == 0) return launch_gemm<1, 4, 4, 1, 16, true>(p, 1, s);
-    if (Cout % 64 == 0) return launch_gemm<1, 2, 4, 1, 16, true>(p, 1, s);
-    return launch_gemm<1, 1, 4, 1, 16, true>(p, 1, s);
+    return launch_conv(p, 1, s);
 }
 
 // ---- Downsample2x of the encoder (basic_vae.py:31-37): F.pad(x, (0,1,0,1)) then Conv2d(k=3, stride=2, padding=0) -------------
@@ -438,10 +635,7 @@ extern "C" int varhip_conv3x3_s2_nhwc_f32(const float* in, const float* w, const
     const double npix = (double)B * H * W;
     VhScope scope(VH_FAM_CONV, (hipStream_t)stream, 2.0 * npix * Cout * 9.0 * Cin, 4.0 * (npix * 4 * Cin + npix * Cout + 9.0 * Cin * Cout));
     hipStream_t s = (hipStream_t)stream;
-    if (Cout % 160 == 0) return launch_gemm<1, 5, 4, 1, 16, true>(p, 1, s);
-    if (Cout % 128 == 0) return launch_gemm<1, 4, 4, 1, 16, true>(p, 1, s);
-    if (Cout % 64 == 0) return launch_gemm<1, 2, 4, 1, 16, true>(p, 1, s);
-    return launch_gemm<1, 1, 4, 1, 16, true>(p, 1, s);
+    return launch_conv(p, 1, s);
 }
 
 // ---- nearest-2x upsample + 3x3 conv as four 2x2 convs on the low-resolution map ("phase decomposition") ---------------------
@@ -484,8 +678,5 @@ extern "C" int varhip_upconv_phase_f32(const float* in, const float* w_phase, co
     const double npix = (double)B * H * W;
     VhScope scope(VH_FAM_CONV, (hipStream_t)stream, 2.0 * npix * Cout * 4.0 * Cin, 4.0 * (npix * Cin / 4.0 + npix * Cout + 16.0 * Cin * Cout));
     hipStream_t s = (hipStream_t)stream;
-    if (Cout % 160 == 0) return launch_gemm<1, 5, 4, 1, 16, true>(p, 4, s);
-    if (Cout % 128 == 0) return launch_gemm<1, 4, 4, 1, 16, true>(p, 4, s);
-    if (Cout % 64 == 0) return launch_gemm<1, 2, 4, 1, 16, true>(p, 4, s);
-    return launch_gemm<1, 1, 4, 1, 16, true>(p, 4, s);
+    return launch_conv(p, 4, s);
 }
