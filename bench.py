@@ -91,7 +91,7 @@ def main():
         fam = max(('gemm', 'conv3x3', 'attn'), key=lambda k: tt[k]['ms'])
         f = tt[fam]
         achieved = f['flops'] / (f['ms'] * 1e-3) / 1e12 if f['ms'] > 0 else 0.0
-        kname = {'gemm': 'k_mfma_gemm<2,2,2,2,32,false,true>', 'conv3x3': 'k_mfma_gemm<1,5,4,1,16,true,true>', 'attn': 'k_attn_cached'}[fam]
+        kname = {'gemm': 'k_dma_gemm<4,4,false>', 'conv3x3': 'k_dma_gemm<4,5,true>', 'attn': 'k_attn_cached'}[fam]
         traffic = None                                                       # HBM-side bytes per launch from a separate rocprofv3 --pmc pass
         try:
             pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))['kernels'].get(kname)

@@ -160,7 +160,7 @@ void run(const char* name, const float* A, const float* W, float* out, int M, in
 
 // ---- variant B: LDS-DMA staging (global_load_lds 16 B, XOR-swizzled source), MFMA 16x16x4, ds_read_b32 operands, natural k order ----
 typedef float f32x4v __attribute__((ext_vector_type(4)));
-template <int WT /*wave tile = WT x WT*/, int NSTAGE, int BK, int MINW>
+template <int WT /*wave tile = WT x WT*/, int NSTAGE, int BK, int MINW, int PF>
 __global__ void __launch_bounds__(256, MINW) kdma(const float* __restrict__ A, const float* __restrict__ W, float* __restrict__ out, int M, int N, int K) {
     constexpr int BM = 2 * WT, BN = 2 * WT, T = WT / 16, CH = BK / 4 /*16B chunks per row*/, RPI = 64 / CH /*rows per DMA instr*/;
     extern __shared__ __attribute__((aligned(16))) float smem[];      // [NSTAGE][(BM+BN)*BK]
@@ -211,6 +211,7 @@ __global__ void __launch_bounds__(256, MINW) kdma(const float* __restrict__ A, c
         if (kt + 1 < nk) dma_tile(kt + 1, (kt + 1) % NSTAGE);
         const float* sA = smem + cur * STAGE + (wm * WT + r16) * BK + kq;
         const float* sB = smem + cur * STAGE + BM * BK + (wn * WT + r16) * BK + kq;
+        if (PF == 0) {
 #pragma unroll
         for (int s = 0; s < CH; ++s) {
             float af[T], bf[T];
@@ -224,6 +225,32 @@ __global__ void __launch_bounds__(256, MINW) kdma(const float* __restrict__ A, c
 #pragma unroll
                 for (int j = 0; j < T; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
+        } else {
+            // fragment prefetch: the operands of step s+1 are read while the MFMAs of step s run
+            float af[2][T], bf[2][T];
+            {
+                const int sl = ((0 ^ (r16 & (CH - 1))) << 2);
+#pragma unroll
+                for (int i = 0; i < T; ++i) af[0][i] = sA[i * 16 * BK + sl];
+#pragma unroll
+                for (int j = 0; j < T; ++j) bf[0][j] = sB[j * 16 * BK + sl];
+            }
+#pragma unroll
+            for (int s = 0; s < CH; ++s) {
+                if (s + 1 < CH) {
+                    const int sl = (((s + 1) ^ (r16 & (CH - 1))) << 2);
+#pragma unroll
+                    for (int i = 0; i < T; ++i) af[(s + 1) & 1][i] = sA[i * 16 * BK + sl];
+#pragma unroll
+                    for (int j = 0; j < T; ++j) bf[(s + 1) & 1][j] = sB[j * 16 * BK + sl];
+                }
+#pragma unroll
+                for (int i = 0; i < T; ++i)
+#pragma unroll
+                    for (int j = 0; j < T; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s & 1][i], bf[s & 1][j], acc[i][j], 0, 0, 0);
+                if (PF == 2) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
         __syncthreads();
     }
 #pragma unroll
@@ -235,11 +262,11 @@ __global__ void __launch_bounds__(256, MINW) kdma(const float* __restrict__ A, c
                 out[(size_t)(m0 + wm * WT + i * 16 + kq * 4 + e) * N + n0 + wn * WT + j * 16 + r16] = acc[i][j][e];
 }
 
-template <int WT, int NSTAGE, int BK, int MINW>
+template <int WT, int NSTAGE, int BK, int MINW, int PF = 0>
 void run_dma(const char* name, const float* A, const float* W, float* out, int M, int N, int K, const float* ref) {
     constexpr int BM = 2 * WT, BN = 2 * WT;
     size_t lds = (size_t)NSTAGE * (BM + BN) * BK * 4;
-    auto kf = kdma<WT, NSTAGE, BK, MINW>;
+    auto kf = kdma<WT, NSTAGE, BK, MINW, PF>;
     hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid((M / BM) * (N / BN));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -268,13 +295,11 @@ int main(int argc, char** argv) {
     run<2, 2, 2, 2, 32, 0, 1>("baseline 128x128 BK32", A, W, out, M, N, K);
     float* ref; hipMalloc(&ref, (size_t)M * N * 4);
     run<2, 2, 2, 2, 32, 0, 1>("baseline again (reference output)", A, W, ref, M, N, K);
-    run<2, 2, 2, 2, 32, 16, 1>("reg-staged, 2-deep prefetch BK32", A, W, out, M, N, K);
-    { std::vector<float> a(4096), b(4096); hipMemcpy(a.data(), out, 16384, hipMemcpyDeviceToHost); hipMemcpy(b.data(), ref, 16384, hipMemcpyDeviceToHost); int bad = 0; for (int i = 0; i < 4096; ++i) bad += a[i] != b[i]; printf("   2-deep mismatches %d\n", bad); }
-    run<2, 2, 2, 2, 16, 16, 1>("reg-staged, 2-deep prefetch BK16", A, W, out, M, N, K);
     run_dma<64, 2, 32, 1>("DMA 128x128 BK32 2 stages", A, W, out, M, N, K, ref);
-    run_dma<64, 2, 16, 1>("DMA 128x128 BK16 2 stages", A, W, out, M, N, K, ref);
-    run_dma<64, 2, 16, 4>("DMA 128x128 BK16 2 stages minw4", A, W, out, M, N, K, ref);
-    run_dma<64, 3, 16, 3>("DMA 128x128 BK16 3 stages minw3", A, W, out, M, N, K, ref);
+    run_dma<64, 2, 32, 1, 1>("DMA 128x128 BK32 2 stages frag-prefetch", A, W, out, M, N, K, ref);
+    run_dma<64, 2, 32, 1, 2>("DMA 128x128 BK32 2 stages frag-prefetch+schedbar", A, W, out, M, N, K, ref);
     run_dma<32, 2, 32, 1>("DMA 64x64 BK32 2 stages", A, W, out, M, N, K, ref);
+    run_dma<32, 2, 32, 1, 1>("DMA 64x64 BK32 2 stages frag-prefetch", A, W, out, M, N, K, ref);
+    run_dma<32, 2, 32, 1, 2>("DMA 64x64 BK32 2 stages frag-prefetch+schedbar", A, W, out, M, N, K, ref);
     return 0;
 }
