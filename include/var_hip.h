@@ -192,6 +192,21 @@ int varhip_quant_residual_f32(const int64_t* idx, const float* codebook, const i
 /* out[i] = keep[i] ? gt[i] : sampled[i]   — VAR.inpainting's torch.where(mask, gt_tokens, sampled_tokens) (var.py:312-328, fork) */
 int varhip_token_select_i64(const uint8_t* keep, const int64_t* gt, const int64_t* sampled, int64_t* out, int64_t n, varhip_stream_t stream);
 
+/* ---- VAR.smooth_sampling (fork, var.py:367-572) ----------------------------------------------------------
+ * Neighbour table of the codebook (var.py:459-462: cdist + argsort + [:, :n]): nbr_idx[v][c] = the c-th nearest code of v
+ * (c = 0 is v itself), nbr_dist[v][c] its L2 distance; ascending distance, ties by index.  Distances are the direct form
+ * sqrt(sum (a-b)^2), one fma chain over the channels (the reference's BLAS-based cdist differs from it by rounding only).
+ * codebook: [V][D], V <= 8192, 1 <= n <= V. */
+int varhip_neighbor_table_f32(const float* codebook, int V, int D, int n, int32_t* nbr_idx, float* nbr_dist, varhip_stream_t stream);
+/* One scale's selection (var.py:482-537).  logits: [2B][l][V] (CFG pair), gt: [B*l] ground-truth tokens of the scale.
+ *   lp = log_softmax((1+t)*cond - t*uncond);  candidates = nbr_idx[gt][0..n);
+ *   use_thr == 0: the first cand_count candidates are valid;  use_thr != 0: those with dist <= d0 + (thr - d0)*ratio;
+ *   idx_out = the valid candidate with the largest lp (first on ties; none valid -> candidate 0, maxval -inf),
+ *   maxval_out = its lp, distlp_out = log_softmax(-nbr_dist[gt][0..n))[winner];  cfg_out (nullable): the combined logits [B*l][V]. */
+int varhip_smooth_select_f32(const float* logits, const int64_t* gt, const int32_t* nbr_idx, const float* nbr_dist, int n,
+                             int cand_count, int use_thr, float thr, float ratio, int B, int l, int V, double t_cfg,
+                             int64_t* idx_out, float* maxval_out, float* distlp_out, float* cfg_out, varhip_stream_t stream);
+
 /* ---- nearest-codebook lookup (encode side; quant.py:150-157) --------------------------------------------
  * idx[n] = argmin_v ( |z_n|^2 + |e_v|^2 - 2 z_n.e_v ), first index on ties; z: [N][Cv], codebook: [V][Cv] */
 int varhip_nearest_code_f32(const float* z, const float* codebook, int64_t* idx_out, int N, int V, int Cv, varhip_stream_t stream);

@@ -714,3 +714,67 @@ int varref_nearest_code_f32(const float* z, const float* codebook, int64_t* idx_
     free(ee);
     return 0;
 }
+
+/* ================================================================================================================
+ * VAR.smooth_sampling (fork, reference models/var.py:367-572).
+ * Neighbour table (var.py:459-462: torch.cdist -> argsort -> [:, :n]).  Restated with the direct-form distance
+ * sqrt(sum (a-b)^2) as one fma chain and a total order (distance, then index): the reference's own table depends on its
+ * BLAS (cdist's |a|^2+|b|^2-2ab form) and on an unstable argsort, so only well-separated neighbours are comparable with it. */
+int varref_neighbor_table_f32(const float* codebook, int V, int D, int n, int32_t* nbr_idx, float* nbr_dist) {
+    if (V <= 0 || V > 8192 || D <= 0 || n <= 0 || n > V) return VARHIP_EINVAL;
+#pragma omp parallel for schedule(static)
+    for (int v = 0; v < V; ++v) {
+        sortent_t* s = (sortent_t*)malloc(sizeof(sortent_t) * V);
+        float* dd = (float*)malloc(sizeof(float) * V);
+        const float* a = codebook + (int64_t)v * D;
+        for (int u = 0; u < V; ++u) {
+            const float* b = codebook + (int64_t)u * D;
+            float acc = 0.0f;
+            for (int c = 0; c < D; ++c) { float d = a[c] - b[c]; acc = vm_fma(d, d, acc); }
+            dd[u] = vm_sqrt(acc);
+            s[u].key = vm_float_key(dd[u]); s[u].idx = u;
+        }
+        qsort(s, V, sizeof(sortent_t), cmp_sortent);
+        for (int c = 0; c < n; ++c) { nbr_idx[(int64_t)v * n + c] = s[c].idx; nbr_dist[(int64_t)v * n + c] = dd[s[c].idx]; }
+        free(s); free(dd);
+    }
+    return 0;
+}
+
+/* one scale of the selection (var.py:482-537): CFG combine, log_softmax, candidates = nearest neighbours of the ground-truth
+ * token, count or threshold validity, arg-max of the log-probability (first index on ties; nothing valid -> candidate 0),
+ * and the log-softmax of the negated candidate distances at the winner. */
+int varref_smooth_select_f32(const float* logits, const int64_t* gt, const int32_t* nbr_idx, const float* nbr_dist, int n,
+                             int cand_count, int use_thr, float thr, float ratio, int B, int l, int V, double t_cfg,
+                             int64_t* idx_out, float* maxval_out, float* distlp_out, float* cfg_out) {
+    if (B <= 0 || l <= 0 || V <= 0 || n <= 0 || n > V || (!use_thr && (cand_count < 1 || cand_count > n))) return VARHIP_EINVAL;
+    const float ca = (float)(1.0 + t_cfg), cb = (float)t_cfg;
+    const int64_t rows = (int64_t)B * l;
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < rows; ++r) {
+        const float* lc = logits + r * V; const float* lu = logits + (rows + r) * V;
+        float* x = (float*)malloc(sizeof(float) * 2 * V); float* e = x + V;
+        float m = -INFINITY;
+        for (int i = 0; i < V; ++i) { float a = ca * lc[i]; float b = cb * lu[i]; x[i] = a - b; m = vm_max(m, x[i]); }
+        for (int i = 0; i < V; ++i) e[i] = vm_exp(x[i] - m);
+        const float ls = vm_log(canon_sum256(e, V));
+        if (cfg_out) memcpy(cfg_out + r * V, x, sizeof(float) * V);
+        const int32_t* ni = nbr_idx + gt[r] * n; const float* nd = nbr_dist + gt[r] * n;
+        const float d0 = nd[0];
+        const float eff = d0 + (thr - d0) * ratio;
+        int best = 0; float bl = -INFINITY; float dmax = -INFINITY;
+        for (int c = 0; c < n; ++c) {
+            float lp = (x[ni[c]] - m) - ls;
+            int valid = use_thr ? (nd[c] <= eff) : (c < cand_count);
+            if (!valid) lp = -INFINITY;
+            if (lp > bl) { bl = lp; best = c; }
+            dmax = vm_max(dmax, -nd[c]);
+        }
+        float* ed = (float*)malloc(sizeof(float) * n);
+        for (int c = 0; c < n; ++c) ed[c] = vm_exp(-nd[c] - dmax);
+        const float dls = vm_log(canon_sum256(ed, n));
+        idx_out[r] = ni[best]; maxval_out[r] = bl; distlp_out[r] = (-nd[best] - dmax) - dls;
+        free(ed); free(x);
+    }
+    return 0;
+}

@@ -147,8 +147,10 @@ class OracleVAR:
     def run(self, labels: Sequence[int], noises: List[np.ndarray], cfg: float, top_k: int, top_p: float,
             force_idx: Optional[np.ndarray] = None, decode: bool = True, keep_masked: bool = False,
             gt_tokens: Optional[np.ndarray] = None, keep_mask: Optional[np.ndarray] = None,
-            more_smooth: bool = False, gumbel_noises: Optional[List[np.ndarray]] = None):
-        """Returns dict(img, idx [B,L], logits [per scale 2B,l,V], f_hat [per scale, NCHW], pooled [per scale, NCHW])."""
+            more_smooth: bool = False, gumbel_noises: Optional[List[np.ndarray]] = None, smooth: Optional[dict] = None):
+        """Returns dict(img, idx [B,L], logits [per scale 2B,l,V], f_hat [per scale, NCHW], pooled [per scale, NCHW]).
+        smooth = dict(gt=[B,L] tokens, n=int, thr=float|None): VAR.smooth_sampling (var.py:367-572) — the sampler is replaced by
+        the neighbour-candidate selection; adds sum_ll / sum_dist_ll / maxval / distlp to the result."""
         Lf, sd = self.L_, self.sd
         B, C, H, S = len(labels), self.C, self.H, len(self.pns)
         B2, P, Cv, V = 2 * B, self.pns[-1], self.Cv, self.V
@@ -205,8 +207,25 @@ class OracleVAR:
                 idx = np.empty((B * l,), np.int64)
                 masked = np.empty((B * l, V), np.float32) if (keep_masked or more_smooth) else None
                 t = cfg * (si / (S - 1))                                       # var.py:161,172
-                _ck(Lf['cfg_sample_f32'](_p(logits), _p(f32(noises[draws])), _p(idx), _p(masked), B, l, V, float(t), int(top_k), float(top_p)), 'cfg_sample')
-                draws += 1
+                if smooth is not None:                                         # var.py:484-537 (fork): candidates = neighbours of the gt token
+                    n = int(smooth['n']); thr = smooth.get('thr'); ratio = si / (S - 1)
+                    if 'nbr' not in self._wt:
+                        ni = np.empty((V, n), np.int32); nd = np.empty((V, n), np.float32)
+                        _ck(Lf['neighbor_table_f32'](_p(f32(codebook)), V, Cv, n, _p(ni), _p(nd)), 'neighbor_table')
+                        self._wt['nbr'] = (n, ni, nd)
+                    n0, ni, nd = self._wt['nbr']
+                    assert n0 == n
+                    gs = np.ascontiguousarray(smooth['gt'][:, cur - l:cur], dtype=np.int64).reshape(-1)
+                    mv = np.empty(B * l, np.float32); dl = np.empty(B * l, np.float32)
+                    _ck(Lf['smooth_select_f32'](_p(logits), _p(gs), _p(ni), _p(nd), n, 1 + int((n - 1) * ratio), int(thr is not None),
+                                                float(thr if thr is not None else 0.0), float(ratio), B, l, V, float(t), _p(idx), _p(mv), _p(dl), _p(masked)), 'smooth_select')
+                    out.setdefault('maxval', []).append(mv); out.setdefault('distlp', []).append(dl)
+                    # var.py:537: new_tensor(max_vals) takes sampled_tokens' dtype (int64): each value is truncated toward zero before the sum
+                    out['sum_ll'] = np.float32(out.get('sum_ll', np.float32(0.0)) + np.float32(np.trunc(mv.astype(np.float64)).sum()))
+                    out['sum_dist_ll'] = np.float32(out.get('sum_dist_ll', np.float32(0.0)) + dl.sum(dtype=np.float32))
+                else:
+                    _ck(Lf['cfg_sample_f32'](_p(logits), _p(f32(noises[draws])), _p(idx), _p(masked), B, l, V, float(t), int(top_k), float(top_p)), 'cfg_sample')
+                    draws += 1
                 if gt_tokens is not None:                                      # torch.where(mask, gt, sampled): var.py:326-328
                     km = np.ascontiguousarray(keep_mask[:, cur - l:cur]).astype(np.uint8).reshape(-1)
                     gs = np.ascontiguousarray(gt_tokens[:, cur - l:cur], dtype=np.int64).reshape(-1)

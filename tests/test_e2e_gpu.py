@@ -135,8 +135,8 @@ def test_public_api_and_properties():
     assert torch.equal(full[1:3], sub), 'an image must not depend on its batch neighbours'
     with pytest.raises(ValueError):
         eng.sample(2, torch.tensor([5, 1001], device='cuda'), None, 1.5, 0, 0.0)
-    with pytest.raises(NotImplementedError):
-        var.smooth_sampling()
+    with pytest.raises(ValueError):
+        var.smooth_sampling(torch.zeros(2, 3, dtype=torch.long, device='cuda'), 4, label=labels)       # gt_tokens must be (B, L)
 
 
 def test_incremental_fhat_equals_embed_to_fhat_and_decoder_api():
@@ -194,6 +194,51 @@ def test_inpainting_vs_reference_and_oracle(name, golden_dir):
     ok, m = util.diff_report('all-kept inpainting == idxBl_to_img', full.cpu().numpy(), ref_img.cpu().numpy(), atol=2e-5); print(m); assert ok, m
     with pytest.raises(ValueError):
         var.inpainting(gt, mask[:, :-1], label=labels)
+
+
+@pytest.mark.parametrize('name', ['smooth_t_pn12345_count', 'smooth_t_pn12345_thr', 'smooth_t_pn12345_count_ms', 'smooth_d16_pn123_count'])
+def test_smooth_sampling_vs_reference_and_oracle(name, golden_dir):
+    """VAR.smooth_sampling (fork API, var.py:367-572) on HIP: chosen tokens identical to the reference's run, both log-likelihood
+    sums as in tests/test_oracle_vs_golden.py, and HIP == oracle bit for bit (tokens, per-row values, f_hat)."""
+    import json
+    z = np.load(f'{golden_dir}/{name}.npz')
+    meta = json.loads(str(z['meta']))
+    vae, var = build_models(meta)
+    B = len(meta['labels'])
+    labels = torch.tensor(meta['labels'], device='cuda')
+    gt = torch.from_numpy(z['gt'].astype(np.int64)).cuda()
+    gum = None
+    if meta['more_smooth']:
+        g = torch.Generator(); g.manual_seed(meta['seed'])
+        gum = [torch.empty(B, pn * pn, meta['V']).exponential_(generator=g).view(-1, meta['V']) for pn in meta['patch_nums']]
+    eng = var.engine()
+    img = eng.sample(B, labels, None, meta['cfg'], 0, 0.0, trace=True, more_smooth=meta['more_smooth'], gumbel_noises=gum,
+                     smooth=dict(gt=gt, n=meta['n'], thr=meta['thr']))
+    idx = torch.cat(eng.last_trace['idx'], dim=1).cpu().numpy()
+    f_hat = eng.last_trace['f_hat'][-1].cpu().numpy()
+    sll, sdl = (float(t) for t in eng.last_smooth)
+    nrows = z['gt'].size
+    if 'idx' in z.files:
+        ok, m = util.diff_report(f'{name} tokens vs reference', idx.astype(np.int32), z['idx']); print(m); assert ok, m
+    assert abs(sll - float(z['sum_ll'])) <= max(1.0, nrows / 100), (sll, float(z['sum_ll']))
+    assert abs(sdl - float(z['sum_dist_ll'])) <= nrows * 2.0 * float(z['self_dist_max']) + 1e-3, (sdl, float(z['sum_dist_ll']))
+    ok, m = util.diff_report(f'{name} image vs reference', img.cpu().numpy(), z['img'], atol=2e-3 if meta['more_smooth'] else 1e-3); print(m); assert ok, m
+    util.ensure_oracle_built()
+    from oracle.var_oracle import OracleVAR
+    var_sd, vae_sd = util.make_weights(meta)
+    r = OracleVAR(var_sd, vae_sd, meta['patch_nums'], meta['depth']).run(meta['labels'], None, meta['cfg'], 0, 0.0, more_smooth=meta['more_smooth'],
+                                                                           gumbel_noises=None if gum is None else [a.numpy() for a in gum],
+                                                                           smooth=dict(gt=z['gt'].astype(np.int64), n=meta['n'], thr=meta['thr']))
+    ok, m = util.diff_report(f'{name} tokens vs oracle', idx, r['idx']); print(m); assert ok, m
+    ok, m = util.diff_report(f'{name} f_hat vs oracle (exact)', f_hat, r['f_hat'][-1]); print(m); assert ok, m
+    assert sll == float(r['sum_ll']), (sll, float(r['sum_ll']))
+    assert abs(sdl - float(r['sum_dist_ll'])) <= 1e-4 * nrows        # same addends; torch's sum order is its own
+    # public API: deterministic, returns the documented triple
+    a = var.smooth_sampling(gt, meta['n'], label=labels, g_seed=3, cfg=meta['cfg'], more_smooth=meta['more_smooth'], neighbor_threshold=meta['thr'])
+    b = var.smooth_sampling(gt, meta['n'], label=labels, g_seed=3, cfg=meta['cfg'], more_smooth=meta['more_smooth'], neighbor_threshold=meta['thr'])
+    assert torch.equal(a[0], b[0]) and a[0].shape == img.shape and float(a[1]) == float(b[1]) and a[1].dtype == torch.float32
+    if not meta['more_smooth']:
+        assert torch.equal(a[0], img) and float(a[1]) == sll
 
 
 def test_more_smooth_vs_oracle_and_reference(golden_dir):

@@ -137,6 +137,35 @@ def test_gemm_qkv_fused_epilogue_exact(B2, l, H, K, pos0, Lmax, l2):
         check(f'gemm_qkv {nm}', g, w)
 
 
+@pytest.mark.parametrize('V,D,n', [(4096, 32, 6), (512, 8, 512), (300, 5, 17), (8192, 16, 3)])
+def test_neighbor_table_exact(V, D, n):
+    """smooth_sampling's neighbour table: ascending distance, ties by index (duplicated codes force ties), self first"""
+    rng = np.random.default_rng(V + n)
+    cb = rnd(rng, V, D)
+    cb[7] = cb[3]; cb[V - 1] = cb[3]                                   # exact duplicates -> zero distances and ties
+    ni = np.zeros((V, n), np.int32); nd = np.zeros((V, n), np.float32)
+    (gi, gd), (wi, wd) = both('neighbor_table_f32', [cb, V, D, n, ni, nd], [4, 5])
+    check('neighbor idx', gi, wi); check('neighbor dist', gd, wd)
+    assert gi[3, 0] == 3 and (n < 3 or (gi[3, 1] == 7 and gi[3, 2] == V - 1)) and np.all(np.diff(gd, axis=1) >= 0)
+
+
+@pytest.mark.parametrize('B,l,V,n,cc,thr', [(2, 9, 4096, 6, 3, None), (3, 4, 4096, 8, 8, 2.5), (2, 1, 512, 300, 300, None), (2, 5, 1024, 16, 1, 0.0), (1, 3, 4096, 5, 5, 1e9)])
+def test_smooth_select_exact(B, l, V, n, cc, thr):
+    rng = np.random.default_rng(B * l + n)
+    D = 8
+    cb = rnd(rng, V, D)
+    ni = np.zeros((V, n), np.int32); nd = np.zeros((V, n), np.float32)
+    L, _ = _setup()
+    assert L['neighbor_table_f32'](ctypes.c_void_p(cb.ctypes.data), V, D, n, ctypes.c_void_p(ni.ctypes.data), ctypes.c_void_p(nd.ctypes.data)) == 0
+    logits = rnd(rng, 2 * B * l, V, scale=3.0)
+    gt = rng.integers(0, V, size=B * l).astype(np.int64)
+    idx = np.zeros(B * l, np.int64); mv = np.zeros(B * l, np.float32); dl = np.zeros(B * l, np.float32); cfgo = np.zeros((B * l, V), np.float32)
+    outs_h, outs_r = both('smooth_select_f32', [logits, gt, ni, nd, n, cc, int(thr is not None), float(thr or 0.0), 0.625, B, l, V, 0.9375, idx, mv, dl, cfgo],
+                          [13, 14, 15, 16])
+    for nm, g, w in zip(('idx', 'maxval', 'distlp', 'cfg logits'), outs_h, outs_r):
+        check(f'smooth_select {nm}', g, w)
+
+
 @pytest.mark.parametrize('B2,l,H,curL,Lmax', [(4, 1, 2, 1, 14), (4, 4, 2, 5, 14), (4, 9, 2, 14, 14), (2, 25, 2, 55, 55), (2, 100, 3, 255, 300), (2, 256, 2, 680, 680), (1, 169, 1, 424, 680)])
 def test_attn_cached_exact(B2, l, H, curL, Lmax):
     rng = np.random.default_rng(l * 3 + curL)

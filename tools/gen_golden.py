@@ -195,6 +195,53 @@ def run_more_smooth():
     print(f'[gen_golden] more_smooth_t_pn12345: img mean {img.mean():.4f}', flush=True)
 
 
+def run_smooth_sampling():
+    """VAR.smooth_sampling fixtures (fork, reference models/var.py:367-572): every position takes, among the nearest codebook
+    neighbours of its ground-truth token, the one with the highest CFG log-probability.  Three variants on the tiny config
+    (candidate-count mode, threshold mode, candidate-count + more_smooth) and candidate-count mode on d16 (1,2,3)."""
+    for name, base, n, thr_rank, smooth in (('smooth_t_pn12345_count', 't_pn12345', 6, None, False), ('smooth_t_pn12345_thr', 't_pn12345', 8, 4, False),
+                                            ('smooth_t_pn12345_count_ms', 't_pn12345', 5, None, True), ('smooth_d16_pn123_count', 'd16_pn123', 6, None, False)):
+        cfg = dict(CASES[base])
+        vae, var = build_reference(cfg)
+        z = np.load(os.path.join(GOLD, f'e2e_{base}.npz'))
+        gt = torch.from_numpy(z['idx'].astype(np.int64))
+        B, L = gt.shape
+        gq = torch.Generator(); gq.manual_seed(77)
+        rnd_tok = torch.randint(0, 4096, (B, L), generator=gq)
+        gt = torch.where(torch.rand(B, L, generator=gq) < 0.7, rnd_tok, gt)     # mostly random ground truth: the model disagrees with it often
+        emb = vae.quantize.embedding.weight.detach()
+        d = torch.cdist(emb, emb, p=2)
+        srt = torch.sort(d, dim=1).values
+        thr = None
+        if thr_rank is not None:                       # a threshold that cuts between the thr_rank-th and the next neighbour for a typical token
+            thr = float(0.5 * (srt[:, thr_rank].median() + srt[:, thr_rank + 1].median()))
+        finals, fhats = [], []
+        hk = vae.quantize.embedding.register_forward_hook(lambda m, inp, out: finals.append(inp[0].detach().clone()))
+        orig_next = vae.quantize.get_next_autoregressive_input
+        def get_next(si, SN, f_hat, h):
+            f, nxt = orig_next(si, SN, f_hat, h); fhats.append(f.detach().clone()); return f, nxt
+        vae.quantize.get_next_autoregressive_input = get_next
+        seed = 31
+        with torch.inference_mode():
+            img, sll, sdl = var.smooth_sampling(gt, n, label=torch.tensor(cfg['labels']), g_seed=seed, cfg=cfg['cfg'], more_smooth=smooth, neighbor_threshold=thr)
+        hk.remove()
+        rec = dict(gt=gt.numpy().astype(np.int32), img=img.numpy(), f_hat=fhats[-1].numpy(), sum_ll=np.float64(float(sll)), sum_dist_ll=np.float64(float(sdl)),
+                   self_dist_max=np.float64(float(d.diagonal().max())), gap_min=np.float64(float((srt[:, 1:n + 1] - srt[:, 0:n]).min())))
+        if not smooth: rec['idx'] = torch.cat(finals, 1).numpy().astype(np.int32)        # with more_smooth the embedding lookup is bypassed
+        if smooth:
+            g = torch.Generator(); g.manual_seed(seed)
+            heads = []
+            for pn in cfg['patch_nums']:
+                a = torch.empty(B, pn * pn, 4096).exponential_(generator=g); heads.append(a.view(-1)[:4].numpy().copy())
+            rec['noise_head'] = np.stack(heads)
+        meta = dict(cfg); meta.update(B=B, V=4096, seed=seed, base=base, n=n, thr=thr, more_smooth=smooth, sum_ll_dtype=str(sll.dtype) if torch.is_tensor(sll) else 'float')
+        rec['meta'] = np.array(json.dumps(meta))
+        np.savez_compressed(os.path.join(GOLD, f'{name}.npz'), **rec)
+        moved = int((rec['idx'] != rec['gt']).sum()) if 'idx' in rec else -1
+        print(f'[gen_golden] {name}: n={n} thr={thr} sum_ll={float(sll):.3f} sum_dist_ll={float(sdl):.4f} moved {moved}/{gt.numel()} '
+              f'self-dist max {float(d.diagonal().max()):.2e} min neighbour gap {float(rec["gap_min"]):.2e}', flush=True)
+
+
 def run_encode():
     """encode side + teacher forcing: VQVAE.img_to_post / img_to_idxBl (vqvae.py:65-75), quantize.idxBl_to_var_input
     (quant.py:169-184) and VAR.forward (var.py:192-234, cond_drop_rate 0) on a seeded random image"""
@@ -273,6 +320,7 @@ def main():
         run_case(name, cfg)
     if not args.only or 'inpaint' in args.only: run_inpaint()
     if not args.only or 'more_smooth' in args.only: run_more_smooth()
+    if not args.only or 'smooth_sampling' in args.only: run_smooth_sampling()
     if not args.only or 'encode' in args.only: run_encode()
     if not args.only or 'nearest_code' in args.only: run_nearest_code()
     if not args.only or 'sampler' in args.only: run_sampler_vectors()

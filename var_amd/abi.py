@@ -43,6 +43,8 @@ SIGNATURES = {
     'quant_accum_h_f32': [P, P, P, P, P, F, P, P, I, I, I, I],
     'gumbel_softmax_f32': [P, P, P, L, I, F, F],
     'gemm_qkv_f32':      [P, L, P, L, P, I, I, I, P, F, I, P, P, P, I, I, I, I, I],
+    'neighbor_table_f32': [P, I, I, I, P, P],
+    'smooth_select_f32': [P, P, P, P, I, I, I, F, F, I, I, I, D, P, P, P, P],
 }
 
 EPI_NONE, EPI_GELU, EPI_RESID = 0, 1, 2

@@ -407,6 +407,20 @@ class SamplingEngine:
         N, K = W.shape
         hip.call('gemm_nt_f32', A, K, W, K, bias, out, N, M, N, K, epi, resid, N, gamma, ldg, rpg, 0, 1, 0, 0, 0)
 
+    def neighbor_table(self, n: int):
+        """(idx int32 [V, n], dist float32 [V, n]) nearest codes of every code (var.py:459-462); cached until the codebook changes."""
+        self.refresh()
+        tabs = self.w.setdefault('nbr', {})
+        if n not in tabs:
+            cb = self.w['codebook']
+            V, D = cb.shape
+            idx = torch.empty(V, n, dtype=torch.int32, device=cb.device)
+            dist = torch.empty(V, n, dtype=torch.float32, device=cb.device)
+            hip.call('neighbor_table_f32', cb, V, D, n, idx, dist)
+            tabs.clear()                                        # one n resident at a time
+            tabs[n] = (idx, dist)
+        return tabs[n]
+
     def qkv(self, xn, blk, ws, bi, rows, l, cur):
         """mat_qkv + q/k normalisation + KV-cache append in one launch (basic_var.py:93-109)."""
         C, H = self.var.C, self.var.num_heads
@@ -418,12 +432,15 @@ class SamplingEngine:
     def sample(self, B: int, label_B: torch.Tensor, rng: Optional[torch.Generator], cfg: float, top_k: int, top_p: float,
                noises=None, force_idx: Optional[torch.Tensor] = None, trace: bool = False,
                decode: bool = True, gt_tokens: Optional[torch.Tensor] = None, keep_mask: Optional[torch.Tensor] = None,
-               more_smooth: bool = False, gumbel_noises=None) -> torch.Tensor:
+               more_smooth: bool = False, gumbel_noises=None, smooth: Optional[dict] = None) -> torch.Tensor:
         """label_B: int64 [B] on the device.  noises: optional per-scale Exp(1) tensors [B*l, V] — a list, or a callable
         (si, l) -> tensor (tests inject the CPU generator's stream; var_amd.multi hands each rank its rows); by default they
         are drawn with `exponential_(generator=rng)` exactly as torch.multinomial (helpers.py:19) would.
         gt_tokens/keep_mask [B, L]: VAR.inpainting (var.py:236-364, fork) — kept positions take the given token, the others are
         sampled; a scale whose tokens are all kept skips the head, the sampler and the RNG draw, as the reference does.
+        smooth = dict(gt=[B, L] tokens, n=int, thr=float|None): VAR.smooth_sampling (var.py:367-572, fork) — no sampler, no Exp(1)
+        draw: every position takes the most likely of the nearest codebook neighbours of its ground-truth token; the two
+        accumulated log-likelihoods are left in self.last_smooth.
         force_idx/trace are test hooks (teacher forcing; keep per-scale logits/tokens/f_hat)."""
         var = self.var
         self.refresh()
@@ -457,6 +474,23 @@ class SamplingEngine:
             keep = keep_mask.to(dev).bool()
             keep_u8 = keep.to(torch.uint8).contiguous()
             skip = torch.stack([keep[:, b0:e0].all() for b0, e0 in var.begin_ends]).tolist()      # one host sync for all scales
+
+        sm_gt = sm_ll = sm_dl = None
+        if smooth is not None:
+            if gt_tokens is not None:
+                raise ValueError('smooth sampling and inpainting are separate entry points')
+            sm_gt = smooth['gt'].to(dev, torch.int64).contiguous()
+            sm_n, sm_thr = int(smooth['n']), smooth.get('thr')
+            if tuple(sm_gt.shape) != (B, var.L) or int(sm_gt.min()) < 0 or int(sm_gt.max()) >= V:
+                raise ValueError(f'gt_tokens must be (B, L) token ids in [0, {V})')
+            if not 1 <= sm_n <= V:
+                raise ValueError(f'n must lie in [1, {V}]')
+            nbr_idx, nbr_dist = self.neighbor_table(sm_n)
+            lmax = max(p * p for p in var.patch_nums)
+            sm_val = torch.empty(B * lmax, dtype=torch.float32, device=dev)
+            sm_dlp = torch.empty(B * lmax, dtype=torch.float32, device=dev)
+            sm_ll = torch.zeros((), dtype=torch.float32, device=dev)
+            sm_dl = torch.zeros((), dtype=torch.float32, device=dev)
 
         # prologue (var.py:151-157)
         hip.call('lvl_pos_f32', w['lvl_embed'], w['lvl_1L'], w['pos_1LC'], ws['lvl_pos'], var.L, C)
@@ -499,15 +533,25 @@ class SamplingEngine:
                 hip.call('ln_modulate_f32', x, hn, 2 * C, hn[:, C:], 2 * C, ws['xn'], M, C, l, var.norm_eps)
                 self.gemm(ws['xn'], w['head_w'], w['head_b'], ws['logits'], M)
                 if trace: tr['logits'].append(ws['logits'][:M].view(B2, l, V).clone())
-                # CFG + top-k/top-p + multinomial (var.py:172-175)
-                if noises is not None:        # a list is indexed by draw count: skipped (fully kept) scales draw nothing
-                    noise = (noises(si, l) if callable(noises) else noises[draws]).to(dev, torch.float32).contiguous()
-                    draws += 1
-                else:
-                    noise = torch.empty(B * l, V, dtype=torch.float32, device=dev).exponential_(1, generator=rng)
                 t = cfg * (si / var.num_stages_minus_1) if var.num_stages_minus_1 > 0 else 0.0
                 idx = ws['idx'][:B * l]
-                hip.call('cfg_sample_f32', ws['logits'], noise, idx, masked, B, l, V, float(t), int(top_k), float(top_p))
+                if sm_gt is not None:
+                    # neighbour-candidate selection instead of sampling (var.py:484-537, fork); `masked` receives the CFG logits
+                    r_ = si / var.num_stages_minus_1 if var.num_stages_minus_1 > 0 else 0.0
+                    hip.call('smooth_select_f32', ws['logits'], sm_gt[:, cur - l:cur].contiguous(), nbr_idx, nbr_dist, sm_n, 1 + int((sm_n - 1) * r_),
+                             int(sm_thr is not None), float(sm_thr if sm_thr is not None else 0.0), float(r_), B, l, V, float(t),
+                             idx, sm_val, sm_dlp, masked)
+                    # var.py:537: new_tensor(max_vals) has the tokens' dtype, so every value is truncated to an integer before the sum
+                    sm_ll = sm_ll + sm_val[:B * l].to(torch.int64).sum()
+                    sm_dl = sm_dl + sm_dlp[:B * l].sum()
+                else:
+                    # CFG + top-k/top-p + multinomial (var.py:172-175)
+                    if noises is not None:        # a list is indexed by draw count: skipped (fully kept) scales draw nothing
+                        noise = (noises(si, l) if callable(noises) else noises[draws]).to(dev, torch.float32).contiguous()
+                        draws += 1
+                    else:
+                        noise = torch.empty(B * l, V, dtype=torch.float32, device=dev).exponential_(1, generator=rng)
+                    hip.call('cfg_sample_f32', ws['logits'], noise, idx, masked, B, l, V, float(t), int(top_k), float(top_p))
                 if gt is not None:                                        # torch.where(mask, gt_tokens, sampled) (var.py:326-328)
                     hip.call('token_select_i64', keep_u8[:, cur - l:cur].contiguous(), gt[:, cur - l:cur].contiguous(), idx, idx, B * l)
                 if trace: tr['idx'].append(idx.view(B, l).clone())
@@ -535,6 +579,7 @@ class SamplingEngine:
                 hip.call('next_map_f32', ws['f_hat'], w['word_w'], w['word_b'], ws['lvl_pos'][cur:], x, ws['pooled'], B, P, pq, C, Cv)
                 if trace: tr['pooled'].append(ws['pooled'][:B * pq * pq].view(B, pq, pq, Cv).permute(0, 3, 1, 2).clone())
         self.last_trace = tr
+        self.last_smooth = (sm_ll, sm_dl) if sm_gt is not None else None
         if not decode:
             return ws['f_hat'].permute(0, 3, 1, 2).contiguous()
         return self.dec.decode_nhwc(ws['f_hat'])                          # var.py:190

@@ -154,8 +154,31 @@ class VAR(nn.Module):
         else: self.rng.manual_seed(g_seed); rng = self.rng
         return self.engine().sample(B, label.to(dev).long(), rng, cfg, top_k, top_p, gt_tokens=gt_tokens, keep_mask=mask)
 
-    def smooth_sampling(self, *args, **kwargs):
-        raise NotImplementedError('VAR.smooth_sampling (fork, reference var.py:366-575) is "next" row 4 of SURVEY.md §8(f)')
+    def smooth_sampling(self, gt_tokens: torch.Tensor, n: int, label: Optional[Union[int, torch.LongTensor]] = None,
+                        g_seed: Optional[int] = None, cfg: float = 1.5, more_smooth: bool = False,
+                        neighbor_threshold: Optional[float] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """Fork API (reference var.py:367-572): every position takes, among the `n` nearest codebook neighbours of its
+        ground-truth token (candidate-count mode: the first 1 + int((n-1)*ratio) of them; threshold mode: those within
+        d_min + (neighbor_threshold - d_min)*ratio), the one with the highest CFG log-probability.
+        Returns (image (B,3,H,W) in [0,1], sum of the chosen log-probabilities — each truncated to an integer first, as the
+        reference's `sampled_tokens.new_tensor(max_vals)` does —, sum of log_softmax(-distance) at the chosen candidates).
+        The neighbour table uses the direct-form L2 distance with ties broken by index (var_hip.h), where the reference's
+        torch.cdist/argsort pair leaves both to the BLAS and an unstable sort."""
+        dev = self.lvl_1L.device
+        if dev.type != 'cuda':
+            raise RuntimeError('VAR.smooth_sampling: this build runs the sampling loop on MI355X HIP kernels only (no CPU fallback by design)')
+        B = gt_tokens.shape[0]
+        if label is None:
+            label = torch.multinomial(self.uniform_prob, num_samples=B, replacement=True).reshape(B)
+        elif isinstance(label, int):
+            label = torch.full((B,), fill_value=label, device=dev)
+        if g_seed is None: rng = None
+        else: self.rng.manual_seed(g_seed); rng = self.rng
+        eng = self.engine()
+        img = eng.sample(B, label.to(dev).long(), rng, cfg, 0, 0.0, more_smooth=more_smooth,
+                         smooth=dict(gt=gt_tokens, n=n, thr=None if neighbor_threshold is None else float(neighbor_threshold)))
+        sum_ll, sum_dist_ll = eng.last_smooth
+        return img, sum_ll, sum_dist_ll
 
     # ---- initialisation (reference var.py:577-627) -------------------------------------------------------------------
     def init_weights(self, init_adaln=0.5, init_adaln_gamma=1e-5, init_head=0.02, init_std=0.02, conv_std_or_gain=0.02):
