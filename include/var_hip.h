@@ -145,7 +145,7 @@ int varhip_first_map_f32(const float* class_emb, const int64_t* labels, int num_
  *             (vqvae.py:63 clamp_ and var.py:190 add_(1).mul_(0.5) fused into the last conv);
  *   out_mode 2: [B][Cout][H][W] holding clamp(v,-1,1) only (VQVAE.fhat_to_img's own contract)
  * replaces every Conv2d(k=3) of basic_vae.py (ResnetBlock :48,:51; conv_in :180; conv_out :208; Upsample2x :25)
- * and vqvae.py:49 post_quant_conv.   Constraint: Cin % 16 == 0. */
+ * and vqvae.py:49 post_quant_conv.   Constraint: Cin % 32 == 0 (a K tile of the implicit GEMM lies inside one tap). */
 int varhip_conv3x3_nhwc_f32(const float* in, const float* w, const float* bias, const float* resid, float* out,
                             int B, int H, int W, int Cin, int Cout, int up2, int out_mode, varhip_stream_t stream);
 
@@ -177,7 +177,7 @@ int varhip_nhwc_to_nchw_f32(const float* in, float* out, int B, int C, int HW, v
  * Downsample2x of the encoder (basic_vae.py:31-37): F.pad(x,(0,1,0,1)) + Conv2d(k=3, stride=2): in [B][2H][2W][Cin] -> out [B][H][W][Cout] */
 int varhip_conv3x3_s2_nhwc_f32(const float* in, const float* w, const float* bias, float* out,
                                int B, int H, int W, int Cin, int Cout, varhip_stream_t stream);
-/* image [B][C][HW] -> [B][HW][Cpad] with zero channels C..Cpad-1 (conv kernels need Cin % 16 == 0; zero channels add exact zeros) */
+/* image [B][C][HW] -> [B][HW][Cpad] with zero channels C..Cpad-1 (conv kernels need Cin % 32 == 0; zero channels add exact zeros) */
 int varhip_nchw_to_nhwc_pad_f32(const float* in, float* out, int B, int C, int HW, int Cpad, varhip_stream_t stream);
 /* pooled[b][t][:] = mean of f[b] over the adaptive window of output cell t   (F.interpolate(mode='area'), quant.py:150,183) */
 int varhip_area_pool_f32(const float* f, float* pooled, int B, int P, int pq, int Cv, varhip_stream_t stream);

@@ -1,17 +1,11 @@
 // gemm.hip — fp32 MFMA GEMM (out = epi(A . W^T + bias)) and implicit-GEMM 3x3 convolution for gfx950.
 //
-// Arithmetic contract: each output element is ONE k-ascending fp32 fma chain from 0 — which is exactly what a
-// sequence of v_mfma_f32_32x32x2_f32 into one accumulator computes (cdna_hip_programming.md §3 "FP32-input MFMA").
-// So no split-K and no reordering of k: the result is bit-identical to oracle/var_oracle.c.
+// Arithmetic contract: each output element is ONE k-ascending fp32 fma chain from 0 — which is exactly what a sequence of
+// fp32 MFMAs (v_mfma_f32_16x16x4_f32 or 32x32x2) into one accumulator computes (cdna_hip_programming.md §3 "FP32-input
+// MFMA").  So no split-K and no reordering of k: the result is bit-identical to oracle/var_oracle.c.
 //
-// Tiling: 256 threads = 4 waves; a wave owns (TM*32) x (TN*32) outputs as TM*TN 32x32 accumulators (16 VGPRs each).
-// K is consumed in tiles of BK; both operands are K-contiguous ("NT"), staged global -> registers -> LDS with a
-// one-tile register prefetch and two LDS stages (one barrier per K tile).
-// LDS image of an operand tile: [rows][BK+4]; inside every 8-float chunk the even k's come first, then the odd k's:
-//   position c*8 + 0..3 = k{0,2,4,6},  c*8 + 4..7 = k{1,3,5,7}.
-// MFMA 32x32x2 takes k = lane>>5 from the lane halves, so lane (r, h) reads ONE ds_read_b128 at row r, chunk c,
-// half h and gets its operand for 4 consecutive MFMAs, which walk k = 2j+h, j=0..3, in natural ascending order.
-// Row stride BK+4 floats makes those b128 reads (and the staging b128 writes) bank-conflict free.
+// Two kernels: k_dma_gemm (everything on the hot path: transformer linears, the fused q/k/v GEMM, all 3x3 convolutions of
+// the VQVAE as implicit GEMMs) and k_gemm_any (shapes the DMA kernel cannot take).  Both operands are K-contiguous ("NT").
 #include "common.h"
 
 struct GemmP {
@@ -25,252 +19,41 @@ struct GemmP {
     const float* q_smul; float* q_out; float* q_kc; float* q_vc; float q_plain; int q_l2, q_l, q_pos0, q_Lmax;
 };
 
-template <int TM, int TN, int WGM, int WGN, int BK, bool CONV, bool VEC>
-__global__ void __launch_bounds__(256) k_mfma_gemm(GemmP p) {
-    constexpr int BM = TM * 32 * WGM, BN = TN * 32 * WGN, LDSW = BK + 4, CPR = BK / 8;
-    constexpr int NA = (BM * CPR + 255) / 256, NB = (BN * CPR + 255) / 256;
-    constexpr int STAGE = (BM + BN) * LDSW;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int wm = wave / WGN, wn = wave % WGN;
-
-    // ---- block -> tile: XCD-contiguous remap (blocks b, b+8 share an L2), then grouped order (8 m-tiles per group)
-    int tm_, tn_;
-    {
-        const int nwg = p.tilesM * p.tilesN, bid = blockIdx.x;
-        const int q = nwg >> 3, rem = nwg & 7, xcd = bid & 7, loc = bid >> 3;
-        const int lin = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + loc;
-        const int GM = 8, width = GM * p.tilesN, group = lin / width, first = group * GM;
-        const int gsz = (p.tilesM - first) < GM ? (p.tilesM - first) : GM;
-        tm_ = first + (lin % width) % gsz;
-        tn_ = (lin % width) / gsz;
-    }
-    const int m0 = tm_ * BM, n0 = tn_ * BN;
-    const int bz = blockIdx.z;
-    const float* Ab = p.A + (int64_t)bz * p.sA;
-    const float* Wb = p.W + (int64_t)bz * p.sW;
+// ------------------------------------------------------------------------------------------------------------------
+// k_gemm_any — fallback for operands the DMA kernel cannot take (K % 32 != 0, odd leading dimensions, unaligned pointers):
+// the tiny VAE-attention products of small test configurations.  Same arithmetic contract (one k-ascending fma chain per
+// output: MFMA 32x32x2 walks k = 2s + (lane >> 5)), operands fetched straight from global memory with guarded scalar loads.
+// 4 waves = 2 x 2 tiles of 32 x 32.
+__global__ void __launch_bounds__(256) k_gemm_any(GemmP p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    const int tm = blockIdx.x / p.tilesN, tn = blockIdx.x - tm * p.tilesN, bz = blockIdx.z;
+    const int m0 = tm * 64 + (wave >> 1) * 32, n0 = tn * 64 + (wave & 1) * 32;
+    const int ma = m0 + r, nb = n0 + r;
+    const float* a = p.A + (int64_t)bz * p.sA + (int64_t)(ma < p.M ? ma : 0) * p.lda;
+    const float* w = p.W + (int64_t)bz * p.sW + (int64_t)(nb < p.N ? nb : 0) * p.ldw;
     float* Ob = p.out + (int64_t)bz * p.sO;
-
-    // ---- staging bookkeeping: each thread owns NA chunks of A and NB chunks of W (chunk = 8 consecutive k of one row)
-    int a_row[NA], a_c[NA]; bool a_ok[NA];
-    int a_b[NA], a_y[NA], a_x[NA];              // CONV: pixel coordinates of the row
-    const float* a_ptr[NA];
+    f32x16 acc;
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        const int qq = tid + 256 * i;
-        a_row[i] = qq / CPR; a_c[i] = qq % CPR;
-        const int m = m0 + a_row[i];
-        a_ok[i] = (qq < BM * CPR) && (m < p.M);
-        if (CONV) {
-            const int hw = p.H * p.Wd;
-            const int mm = a_ok[i] ? m : 0;
-            a_b[i] = mm / hw; const int rem2 = mm % hw; a_y[i] = rem2 / p.Wd; a_x[i] = rem2 % p.Wd;
-            a_ptr[i] = Ab;
-        } else {
-            a_ptr[i] = Ab + (int64_t)(a_ok[i] ? m : 0) * p.lda + a_c[i] * 8;
-        }
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int k0 = 0; k0 < p.K; k0 += 2) {
+        const int k = k0 + h;
+        const float av = (ma < p.M && k < p.K) ? a[k] : 0.f, wv = (nb < p.N && k < p.K) ? w[k] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wv, acc, 0, 0, 0);
     }
-    int b_row[NB], b_c[NB]; bool b_ok[NB];
-    const float* b_ptr[NB];
+    const int n = n0 + r;                                          // C/D layout: col = lane & 31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    if (n >= p.N) return;
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        const int qq = tid + 256 * i;
-        b_row[i] = qq / CPR; b_c[i] = qq % CPR;
-        const int n = n0 + b_row[i];
-        b_ok[i] = (qq < BN * CPR) && (n < p.N);
-        b_ptr[i] = Wb + (int64_t)(b_ok[i] ? n : 0) * p.ldw + b_c[i] * 8;
-    }
-
-    // register stage of the next K tile (a 2-deep variant with two sets was measured: no gain here, +60 VGPRs)
-    f32x4 ra0[NA][2], rb0[NB][2];
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-
-    auto load_tile = [&](int kt, f32x4 (&ra)[NA][2], f32x4 (&rb)[NB][2]) {
-        const int k0 = kt * BK;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            bool ok = a_ok[i] && (k0 + a_c[i] * 8 < p.K);
-            const float* src;
-            if (CONV) {
-                const int tap = k0 / p.Cin, ci0 = k0 - tap * p.Cin;
-                int yy, xx;
-                if (p.up2 == 2) {       // phase (bz>>1, bz&1) of a nearest-2x + 3x3 conv folded into a 2x2 conv on the low-res map
-                    yy = a_y[i] + (tap >> 1) - 1 + (bz >> 1); xx = a_x[i] + (tap & 1) - 1 + (bz & 1);
-                } else if (p.up2 == 3) { // stride-2 conv over an input padded by one zero row/column at the bottom/right (Downsample2x)
-                    const int ky = tap / 3, kx = tap - ky * 3;
-                    yy = 2 * a_y[i] + ky; xx = 2 * a_x[i] + kx;
-                } else {
-                    const int ky = tap / 3, kx = tap - ky * 3;
-                    yy = a_y[i] + ky - 1; xx = a_x[i] + kx - 1;
-                }
-                ok = ok && yy >= 0 && xx >= 0 && (p.up2 == 3 ? (yy < p.Hi && xx < p.Wi) : (yy < p.H && xx < p.Wd));
-                const int sy = p.up2 == 1 ? (yy >> 1) : yy, sx = p.up2 == 1 ? (xx >> 1) : xx;
-                src = Ab + (((int64_t)a_b[i] * p.Hi + (ok ? sy : 0)) * p.Wi + (ok ? sx : 0)) * p.Cin + ci0 + a_c[i] * 8;
-            } else {
-                src = a_ptr[i] + k0;
-            }
-            if (VEC) {
-                // fast path (host guarantees K % BK == 0): the address is always valid (rows/pixels are clamped), so the loads are
-                // unconditional and branch-free; rows >= M only feed outputs that are never stored, conv padding is a select
-                ra[i][0] = *(const f32x4*)src; ra[i][1] = *(const f32x4*)(src + 4);
-                if (CONV && !ok) { ra[i][0] = zero4; ra[i][1] = zero4; }
-            } else {            // any K / leading dimension / alignment: element-wise guarded loads (small shapes only)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) ra[i][e >> 2][e & 3] = (ok && k0 + a_c[i] * 8 + e < p.K) ? src[e] : 0.f;
-            }
+    for (int e = 0; e < 16; ++e) {
+        const int m = m0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (m >= p.M) continue;
+        float v = acc[e];
+        if (p.bias) v = v + (p.bias_per_row ? p.bias[m] : p.bias[n]);
+        if (p.epi == VARHIP_EPI_GELU) v = vm_gelu_tanh(v);
+        else if (p.epi == VARHIP_EPI_RESID) {
+            if (p.gamma) v = v * p.gamma[(int64_t)(m / p.rows_per_group) * p.ldg + n];
+            v = p.resid[(int64_t)m * p.ldr + n] + v;
         }
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const bool ok = b_ok[i] && (k0 + b_c[i] * 8 < p.K);
-            const float* src = b_ptr[i] + k0;
-            if (VEC) {
-                rb[i][0] = *(const f32x4*)src; rb[i][1] = *(const f32x4*)(src + 4);      // rows >= N: clamped, never stored
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) rb[i][e >> 2][e & 3] = (ok && k0 + b_c[i] * 8 + e < p.K) ? src[e] : 0.f;
-            }
-        }
-    };
-    auto store_tile = [&](int stage, f32x4 (&ra)[NA][2], f32x4 (&rb)[NB][2]) {
-        float* sA = smem + stage * STAGE;
-        float* sB = sA + BM * LDSW;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            if (tid + 256 * i < BM * CPR) {
-                float* d = sA + a_row[i] * LDSW + a_c[i] * 8;
-                const f32x4 ev = {ra[i][0][0], ra[i][0][2], ra[i][1][0], ra[i][1][2]};
-                const f32x4 od = {ra[i][0][1], ra[i][0][3], ra[i][1][1], ra[i][1][3]};
-                *(f32x4*)d = ev; *(f32x4*)(d + 4) = od;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            if (tid + 256 * i < BN * CPR) {
-                float* d = sB + b_row[i] * LDSW + b_c[i] * 8;
-                const f32x4 ev = {rb[i][0][0], rb[i][0][2], rb[i][1][0], rb[i][1][2]};
-                const f32x4 od = {rb[i][0][1], rb[i][0][3], rb[i][1][1], rb[i][1][3]};
-                *(f32x4*)d = ev; *(f32x4*)(d + 4) = od;
-            }
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    const int nk = (p.K + BK - 1) / BK;
-    // One K tile of MFMAs on LDS stage `cur`.  `mid()` runs in the MIDDLE of the tile: it writes the next tile (loaded into
-    // registers at the top of the iteration) to the other LDS stage — last read one iteration ago, a barrier has passed since —
-    // so the ds_writes hide under matrix work instead of preceding the barrier.
-    auto compute = [&](int cur, auto&& mid) {
-        const float* sA = smem + cur * STAGE + (wm * TM * 32 + r) * LDSW + h * 4;
-        const float* sB = smem + cur * STAGE + BM * LDSW + (wn * TN * 32 + r) * LDSW + h * 4;
-#pragma unroll
-        for (int c = 0; c < CPR; ++c) {
-            if (c == (CPR + 1) / 2) mid();
-            f32x4 af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *(const f32x4*)(sA + i * 32 * LDSW + c * 8);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *(const f32x4*)(sB + j * 32 * LDSW + c * 8);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
-        }
-    };
-    load_tile(0, ra0, rb0);
-    store_tile(0, ra0, rb0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1, ra0, rb0);
-        compute(cur, [&] { if (kt + 1 < nk) store_tile(cur ^ 1, ra0, rb0); });
-        __syncthreads();
-    }
-
-    // ---- epilogue.  C/D layout of a 32x32 accumulator: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5), i.e. 4 bytes per
-    // lane per row.  Each wave transposes one accumulator at a time through a private LDS patch (the K-loop stages are
-    // free now: the loop ended on a barrier) so that a lane owns 4 consecutive columns of a row: bias / gamma / residual
-    // are read and the result is written with 16-byte accesses, 4x fewer memory instructions than the direct layout.
-    constexpr int EPW = 36;
-    float* ep = smem + wave * (32 * EPW);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int tm0 = m0 + (wm * TM + i) * 32, tn0 = n0 + (wn * TN + j) * 32;
-            if (tm0 >= p.M || tn0 >= p.N) continue;                       // wave-uniform
-            if (CONV && p.out_mode != 0) {                                   // last conv: NCHW store of <= 3 channels, direct layout
-                const int n = tn0 + r;
-                if (n < p.N) {
-                    const float bn = p.bias[n];
-                    const int hw = p.H * p.Wd;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int m = tm0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                        if (m >= p.M) continue;
-                        const int b = m / hw, rem2 = m - b * hw;
-                        const float v = vm_min(vm_max(acc[i][j][e] + bn, -1.0f), 1.0f);
-                        Ob[((int64_t)b * p.N + n) * hw + rem2] = p.out_mode == 1 ? (v + 1.0f) * 0.5f : v;
-                    }
-                }
-                continue;
-            }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) ep[((e & 3) + 8 * (e >> 2) + 4 * h) * EPW + r] = acc[i][j][e];
-            const int c4 = (lane & 7) * 4, n = tn0 + c4;
-            const bool full = p.evec && (n + 3 < p.N);
-            f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias && !p.bias_per_row) {
-                if (full) b4 = *(const f32x4*)(p.bias + n);
-                else { for (int e = 0; e < 4; ++e) if (n + e < p.N) b4[e] = p.bias[n + e]; }
-            }
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int row = it * 8 + (lane >> 3), m = tm0 + row;
-                f32x4 v = *(const f32x4*)(ep + row * EPW + c4);
-                if (m >= p.M || n >= p.N) continue;
-                int64_t mo = m;                                             // output row; phase mode scatters to the 2x grid
-                if (CONV && p.up2 == 2) {
-                    const int hw = p.H * p.Wd, b = m / hw, rem2 = m - b * hw, y = rem2 / p.Wd, x = rem2 - y * p.Wd;
-                    mo = ((int64_t)b * (2 * p.H) + 2 * y + (bz >> 1)) * (2 * p.Wd) + 2 * x + (bz & 1);
-                }
-                if (p.bias) { if (p.bias_per_row) { const float bm = p.bias[m]; v[0] = v[0] + bm; v[1] = v[1] + bm; v[2] = v[2] + bm; v[3] = v[3] + bm; }
-                              else { v[0] = v[0] + b4[0]; v[1] = v[1] + b4[1]; v[2] = v[2] + b4[2]; v[3] = v[3] + b4[3]; } }
-                if (p.epi == VARHIP_EPI_GELU) { v[0] = vm_gelu_tanh(v[0]); v[1] = vm_gelu_tanh(v[1]); v[2] = vm_gelu_tanh(v[2]); v[3] = vm_gelu_tanh(v[3]); }
-                if (full) {
-                    if (p.epi == VARHIP_EPI_RESID) {
-                        if (p.gamma) {
-                            const f32x4 g4 = *(const f32x4*)(p.gamma + (int64_t)(m / p.rows_per_group) * p.ldg + n);
-                            v[0] = v[0] * g4[0]; v[1] = v[1] * g4[1]; v[2] = v[2] * g4[2]; v[3] = v[3] * g4[3];
-                        }
-                        const f32x4 r4 = *(const f32x4*)(p.resid + (int64_t)m * p.ldr + n);
-                        v[0] = r4[0] + v[0]; v[1] = r4[1] + v[1]; v[2] = r4[2] + v[2]; v[3] = r4[3] + v[3];
-                    }
-                    *(f32x4*)(Ob + mo * p.ldo + n) = v;
-                } else {
-                    for (int e = 0; e < 4; ++e) {
-                        if (n + e >= p.N) break;
-                        float x = v[e];
-                        if (p.epi == VARHIP_EPI_RESID) {
-                            if (p.gamma) x = x * p.gamma[(int64_t)(m / p.rows_per_group) * p.ldg + n + e];
-                            x = p.resid[(int64_t)m * p.ldr + n + e] + x;
-                        }
-                        Ob[mo * p.ldo + n + e] = x;
-                    }
-                }
-            }
-        }
+        Ob[(int64_t)m * p.ldo + n] = v;
     }
 }
 
@@ -526,19 +309,9 @@ static int launch_dma(GemmP& p, int batch, hipStream_t stream) {
     return vh_launch_status();
 }
 
-template <int TM, int TN, int WGM, int WGN, int BK, bool CONV, bool VEC = true>
-static int launch_gemm(GemmP& p, int batch, hipStream_t stream) {
-    constexpr int BM = TM * 32 * WGM, BN = TN * 32 * WGN;
-    constexpr size_t lds = 2 * (size_t)(BM + BN) * (BK + 4) * sizeof(float);
-    p.tilesM = (p.M + BM - 1) / BM; p.tilesN = (p.N + BN - 1) / BN;
-    auto kfn = k_mfma_gemm<TM, TN, WGM, WGN, BK, CONV, VEC>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
-    dim3 grid(p.tilesM * p.tilesN, 1, batch);
-    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, stream, p);
+static int launch_any(GemmP& p, int batch, hipStream_t stream) {
+    p.tilesM = (p.M + 63) / 64; p.tilesN = (p.N + 63) / 64;
+    hipLaunchKernelGGL(k_gemm_any, dim3(p.tilesM * p.tilesN, 1, batch), dim3(256), 0, stream, p);
     return vh_launch_status();
 }
 
@@ -571,22 +344,17 @@ extern "C" int varhip_gemm_nt_f32(const float* A, int64_t lda, const float* W, i
         case 0: return launch_dma<4, 4>(p, batch, (hipStream_t)stream);
         case 1: return launch_dma<4, 2>(p, batch, (hipStream_t)stream);
         case 2: return launch_dma<2, 2>(p, batch, (hipStream_t)stream);
-        default: return launch_gemm<1, 1, 2, 2, 32, false, false>(p, batch, (hipStream_t)stream);   // any K / alignment: element-wise loads
+        default: return launch_any(p, batch, (hipStream_t)stream);                 // any K / alignment: scalar guarded loads
     }
 }
 
-// tile choice of the implicit-GEMM convolutions: the N tile divides Cout (160/320/640 -> 160 wide)
+// tile choice of the implicit-GEMM convolutions: the N tile divides Cout (160/320/640 -> 160 wide); Cin % 32 == 0 so that a
+// K tile of 32 lies inside one tap
 static int launch_conv(GemmP& p, int batch, hipStream_t s) {
-    if ((p.Cin & 31) == 0) {                   // LDS-DMA kernel: a K tile of 32 lies inside one tap
-        if (p.N % 160 == 0) return launch_dma<4, 5, true>(p, batch, s);
-        if (p.N % 128 == 0) return launch_dma<4, 4, true>(p, batch, s);
-        if (p.N % 64 == 0) return launch_dma<4, 2, true>(p, batch, s);
-        return launch_dma<4, 1, true>(p, batch, s);
-    }
-    if (p.N % 160 == 0) return launch_gemm<1, 5, 4, 1, 16, true>(p, batch, s);
-    if (p.N % 128 == 0) return launch_gemm<1, 4, 4, 1, 16, true>(p, batch, s);
-    if (p.N % 64 == 0) return launch_gemm<1, 2, 4, 1, 16, true>(p, batch, s);
-    return launch_gemm<1, 1, 4, 1, 16, true>(p, batch, s);
+    if (p.N % 160 == 0) return launch_dma<4, 5, true>(p, batch, s);
+    if (p.N % 128 == 0) return launch_dma<4, 4, true>(p, batch, s);
+    if (p.N % 64 == 0) return launch_dma<4, 2, true>(p, batch, s);
+    return launch_dma<4, 1, true>(p, batch, s);
 }
 
 // ---- mat_qkv with the q/k/v post-processing in the epilogue (basic_var.py:93-109): the [M][3C] intermediate never reaches HBM.
@@ -615,7 +383,7 @@ extern "C" int varhip_gemm_qkv_f32(const float* A, int64_t lda, const float* W, 
 
 extern "C" int varhip_conv3x3_nhwc_f32(const float* in, const float* w, const float* bias, const float* resid, float* out,
                                        int B, int H, int W, int Cin, int Cout, int up2, int out_mode, varhip_stream_t stream) {
-    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (Cin & 15) || !bias) return VARHIP_EINVAL;
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (Cin & 31) || !bias) return VARHIP_EINVAL;
     if (up2 && ((H & 1) || (W & 1))) return VARHIP_EINVAL;
     if (out_mode < 0 || out_mode > 2 || (out_mode != 0 && resid)) return VARHIP_EINVAL;
     if ((int64_t)B * H * W >= (1ll << 31)) return VARHIP_EINVAL;
@@ -636,7 +404,7 @@ extern "C" int varhip_conv3x3_nhwc_f32(const float* in, const float* w, const fl
 extern "C" int varhip_conv3x3_s2_nhwc_f32(const float* in, const float* w, const float* bias, float* out,
                                           int B, int H, int W, int Cin, int Cout, varhip_stream_t stream) {
     // in: [B][2H][2W][Cin], out: [B][H][W][Cout]
-    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (Cin & 15) || !bias) return VARHIP_EINVAL;
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (Cin & 31) || !bias) return VARHIP_EINVAL;
     if ((int64_t)B * H * W >= (1ll << 31)) return VARHIP_EINVAL;
     GemmP p{};
     p.A = in; p.W = w; p.bias = bias; p.out = out;
@@ -679,7 +447,7 @@ extern "C" int varhip_upconv_pack_f32(const float* w, float* w_phase, int Cin, i
 extern "C" int varhip_upconv_phase_f32(const float* in, const float* w_phase, const float* bias, float* out,
                                        int B, int H, int W, int Cin, int Cout, varhip_stream_t stream) {
     // in: [B][H/2][W/2][Cin]; out: [B][H][W][Cout]; w_phase from varhip_upconv_pack_f32
-    if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || Cin <= 0 || Cout <= 0 || (Cin & 15) || !bias) return VARHIP_EINVAL;
+    if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || Cin <= 0 || Cout <= 0 || (Cin & 31) || !bias) return VARHIP_EINVAL;
     if ((int64_t)B * H * W >= (1ll << 31)) return VARHIP_EINVAL;
     GemmP p{};
     p.A = in; p.W = w_phase; p.bias = bias; p.out = out; p.resid = nullptr; p.gamma = nullptr;

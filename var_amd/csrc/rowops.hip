@@ -274,7 +274,7 @@ extern "C" int varhip_nchw_to_nhwc_f32(const float* in, float* out, int B, int C
     hipLaunchKernelGGL(k_nchw_to_nhwc, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out, C, HW, tot);
     return vh_launch_status();
 }
-// image (B,3,H,W) -> channels-last with the channel count padded by zeros (the conv kernels want Cin % 16 == 0)
+// image (B,3,H,W) -> channels-last with the channel count padded by zeros (the conv kernels want Cin % 32 == 0)
 __global__ void k_nchw_to_nhwc_pad(const float* __restrict__ in, float* __restrict__ out, int C, int HW, int Cpad, int64_t tot) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // index into out [B][HW][Cpad]
     if (i >= tot) return;

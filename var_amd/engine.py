@@ -69,7 +69,7 @@ class _VaeOps:
         return tuple((p.data_ptr(), p._version) for p in self.vae.parameters())
 
     def _pack(self):
-        """our copies of the weights this engine uses: 3x3 kernels re-laid [Cout][3][3][Cin] (Cin zero-padded to a multiple of 16),
+        """our copies of the weights this engine uses: 3x3 kernels re-laid [Cout][3][3][Cin] (Cin zero-padded to a multiple of 32),
         1x1 kernels as [Cout][Cin] matrices"""
         w = {}
         for k, v in self.vae.state_dict().items():
@@ -78,8 +78,8 @@ class _VaeOps:
             v = _chk(v.detach(), k)
             if v.dim() == 4 and v.shape[-1] == 3:
                 v = v.permute(0, 2, 3, 1).contiguous()               # [Cout][Cin][3][3] -> [Cout][3][3][Cin]
-                if v.shape[3] % 16:
-                    pad = torch.zeros(v.shape[0], 3, 3, (v.shape[3] + 15) // 16 * 16, dtype=v.dtype, device=v.device)
+                if v.shape[3] % 32:
+                    pad = torch.zeros(v.shape[0], 3, 3, (v.shape[3] + 31) // 32 * 32, dtype=v.dtype, device=v.device)
                     pad[..., :v.shape[3]] = v
                     v = pad
                 w[k] = v
