@@ -53,6 +53,48 @@ __global__ void k_phi_accum(const float* __restrict__ up, const float* __restric
     f_hat[i] = f_hat[i] + hmix;
 }
 
+// Same step, staged through LDS: one workgroup per (sample, row y) holds the Phi weights ([co][9*Cv] rows padded by one float
+// -> conflict-free across co) and the three input rows with a zero halo; thread (x, co) walks the identical (ky, kx, ci) fma chain
+// (the zero taps of the halo add exact zeros where the plain kernel skips them).  f_rest (nullable) is the encoder's running residual.
+__global__ void __launch_bounds__(256) k_phi_accum_lds(const float* __restrict__ up, const float* __restrict__ phi_w, const float* __restrict__ phi_b, float ratio,
+                                                       float keep, float* __restrict__ f_hat, float* __restrict__ f_rest, int P, int Cv) {
+    extern __shared__ __attribute__((aligned(16))) float psm[];
+    const int WS = 9 * Cv + 1, RW = (P + 2) * Cv;
+    float* sw = psm;                     // [Cv][WS]
+    float* su = psm + Cv * WS;           // [3][P+2][Cv]
+    const int tid = threadIdx.x, y = blockIdx.x, b = blockIdx.y;
+    for (int i = tid; i < Cv * 9 * Cv; i += 256) { const int co = i / (9 * Cv), k = i - co * 9 * Cv; sw[co * WS + k] = phi_w[i]; }
+    for (int i = tid; i < 3 * RW; i += 256) {
+        const int ky = i / RW, r = i - ky * RW, xx = r / Cv - 1, ci = r % Cv, yy = y + ky - 1;
+        su[i] = (yy >= 0 && yy < P && xx >= 0 && xx < P) ? up[(((int64_t)b * P + yy) * P + xx) * Cv + ci] : 0.f;
+    }
+    __syncthreads();
+    for (int o = tid; o < P * Cv; o += 256) {
+        const int x = o / Cv, co = o - x * Cv;
+        const float* w = sw + co * WS;
+        float acc = 0.f;
+        for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx) {
+                const float* u = su + ky * RW + (x + kx) * Cv;
+                const float* wt = w + (ky * 3 + kx) * Cv;
+                for (int ci = 0; ci < Cv; ++ci) acc = vm_fma(u[ci], wt[ci], acc);
+            }
+        const float conv = acc + phi_b[co];
+        const int64_t i = (((int64_t)b * P + y) * P + x) * Cv + co;
+        const float hmix = su[RW + (x + 1) * Cv + co] * keep + conv * ratio;
+        f_hat[i] = f_hat[i] + hmix;
+        if (f_rest) f_rest[i] = f_rest[i] - hmix;
+    }
+}
+static bool launch_phi_accum(const float* up, const float* phi_w, const float* phi_b, float ratio, float* f_hat, float* f_rest, int B, int P, int Cv, hipStream_t s) {
+    const size_t lds = ((size_t)Cv * (9 * Cv + 1) + 3 * (size_t)(P + 2) * Cv) * sizeof(float);
+    if (lds > 64 * 1024 || B > 65535) return false;             // wide codebooks: the plain kernels
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)k_phi_accum_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); attr_done = true; }
+    hipLaunchKernelGGL(k_phi_accum_lds, dim3(P, B), dim3(256), lds, s, up, phi_w, phi_b, ratio, 1.0f - ratio, f_hat, f_rest, P, Cv);
+    return true;
+}
+
 extern "C" int varhip_quant_accum_f32(const int64_t* idx, const float* codebook, const int32_t* tap_idx, const float* tap_w,
                                       const float* phi_w, const float* phi_b, float ratio, float* up, float* f_hat,
                                       int B, int pn, int P, int Cv, varhip_stream_t stream) {
@@ -62,7 +104,8 @@ extern "C" int varhip_quant_accum_f32(const int64_t* idx, const float* codebook,
     VhScope sc(VH_FAM_OTHER, (hipStream_t)stream, 2.0 * tot * 9 * Cv, 16.0 * tot);
     const unsigned blocks = (unsigned)((tot + 255) / 256);
     hipLaunchKernelGGL(k_gather_up<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, idx, codebook, tap_idx, tap_w, up, B, pn, P, Cv);
-    hipLaunchKernelGGL(k_phi_accum, dim3(blocks), dim3(256), 0, (hipStream_t)stream, up, phi_w, phi_b, ratio, 1.0f - ratio, f_hat, B, P, Cv);
+    if (!launch_phi_accum(up, phi_w, phi_b, ratio, f_hat, nullptr, B, P, Cv, (hipStream_t)stream))
+        hipLaunchKernelGGL(k_phi_accum, dim3(blocks), dim3(256), 0, (hipStream_t)stream, up, phi_w, phi_b, ratio, 1.0f - ratio, f_hat, B, P, Cv);
     return vh_launch_status();
 }
 
@@ -74,7 +117,8 @@ extern "C" int varhip_quant_accum_h_f32(const float* h, const int32_t* tap_idx, 
     VhScope sc(VH_FAM_OTHER, (hipStream_t)stream, 2.0 * tot * 9 * Cv, 16.0 * tot);
     const unsigned blocks = (unsigned)((tot + 255) / 256);
     hipLaunchKernelGGL(k_gather_up<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const int64_t*)nullptr, h, tap_idx, tap_w, up, B, pn, P, Cv);
-    hipLaunchKernelGGL(k_phi_accum, dim3(blocks), dim3(256), 0, (hipStream_t)stream, up, phi_w, phi_b, ratio, 1.0f - ratio, f_hat, B, P, Cv);
+    if (!launch_phi_accum(up, phi_w, phi_b, ratio, f_hat, nullptr, B, P, Cv, (hipStream_t)stream))
+        hipLaunchKernelGGL(k_phi_accum, dim3(blocks), dim3(256), 0, (hipStream_t)stream, up, phi_w, phi_b, ratio, 1.0f - ratio, f_hat, B, P, Cv);
     return vh_launch_status();
 }
 
@@ -105,6 +149,43 @@ __global__ void k_word_embed(const float* __restrict__ pooled, const float* __re
     x_out[i + (int64_t)B * lq * C] = v;
 }
 
+// Cv == 32 (every released VAR): thread n keeps its 32 weights in registers and walks WE_ROWS rows of the pooled map, whose
+// values are wave-uniform LDS broadcasts; stores are coalesced over n.  Same c-ascending fma chain as k_word_embed.
+#define WE_ROWS 16
+__global__ void __launch_bounds__(256) k_word_embed32(const float* __restrict__ pooled, const float* __restrict__ word_w, const float* __restrict__ word_b,
+                                                      const float* __restrict__ lvl_pos, float* __restrict__ x_out, int64_t rows, int lq, int C) {
+    __shared__ __attribute__((aligned(16))) float sp[WE_ROWS * 32];
+    const int tid = threadIdx.x, n = blockIdx.x * 256 + tid;
+    const int64_t r0 = (int64_t)blockIdx.y * WE_ROWS;
+    for (int i = tid; i < WE_ROWS * 32; i += 256) sp[i] = (r0 + i / 32 < rows) ? pooled[r0 * 32 + i] : 0.f;
+    __syncthreads();
+    if (n >= C) return;
+    f32x4 w[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) w[q] = *(const f32x4*)(word_w + (int64_t)n * 32 + q * 4);
+    const float bn = word_b[n];
+    for (int r = 0; r < WE_ROWS; ++r) {
+        const int64_t bt = r0 + r;
+        if (bt >= rows) break;
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const f32x4 pv = *(const f32x4*)(sp + r * 32 + q * 4);
+            acc = vm_fma(pv[0], w[q][0], acc); acc = vm_fma(pv[1], w[q][1], acc); acc = vm_fma(pv[2], w[q][2], acc); acc = vm_fma(pv[3], w[q][3], acc);
+        }
+        const float v = (acc + bn) + lvl_pos[(bt % lq) * C + n];
+        x_out[bt * C + n] = v;
+        x_out[(bt + rows) * C + n] = v;
+    }
+}
+static void launch_word_embed(const float* pooled, const float* word_w, const float* word_b, const float* lvl_pos, float* x_out, int B, int lq, int C, int Cv, hipStream_t s) {
+    const int64_t rows = (int64_t)B * lq, t2 = rows * C;
+    if (Cv == 32 && !(((uintptr_t)word_w) & 15) && (rows + WE_ROWS - 1) / WE_ROWS <= 65535)
+        hipLaunchKernelGGL(k_word_embed32, dim3((C + 255) / 256, (unsigned)((rows + WE_ROWS - 1) / WE_ROWS)), dim3(256), 0, s, pooled, word_w, word_b, lvl_pos, x_out, rows, lq, C);
+    else
+        hipLaunchKernelGGL(k_word_embed, dim3((unsigned)((t2 + 255) / 256)), dim3(256), 0, s, pooled, word_w, word_b, lvl_pos, x_out, B, lq, C, Cv);
+}
+
 extern "C" int varhip_next_map_f32(const float* f_hat, const float* word_w, const float* word_b, const float* lvl_pos,
                                    float* x_out, float* pooled, int B, int P, int pq, int C, int Cv, varhip_stream_t stream) {
     if (B <= 0 || P <= 0 || pq <= 0 || pq > P || C <= 0 || Cv <= 0 || !pooled) return VARHIP_EINVAL;
@@ -112,7 +193,8 @@ extern "C" int varhip_next_map_f32(const float* f_hat, const float* word_w, cons
     VhScope sc(VH_FAM_OTHER, (hipStream_t)stream, 2.0 * B * lq * (double)C * Cv, 8.0 * B * lq * (double)C);
     const int64_t t1 = (int64_t)B * lq * Cv, t2 = (int64_t)B * lq * C;
     hipLaunchKernelGGL(k_area_pool, dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, f_hat, pooled, B, P, pq, Cv);
-    hipLaunchKernelGGL(k_word_embed, dim3((unsigned)((t2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pooled, word_w, word_b, lvl_pos, x_out, B, lq, C, Cv);
+    (void)t2;
+    launch_word_embed(pooled, word_w, word_b, lvl_pos, x_out, B, lq, C, Cv, (hipStream_t)stream);
     return vh_launch_status();
 }
 
@@ -131,7 +213,7 @@ extern "C" int varhip_word_embed_f32(const float* pooled, const float* word_w, c
     if (B <= 0 || lq <= 0 || C <= 0 || Cv <= 0) return VARHIP_EINVAL;
     const int64_t t2 = (int64_t)B * lq * C;
     VhScope sc(VH_FAM_OTHER, (hipStream_t)stream, 2.0 * t2 * Cv, 8.0 * t2);
-    hipLaunchKernelGGL(k_word_embed, dim3((unsigned)((t2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pooled, word_w, word_b, lvl_pos, x_out, B, lq, C, Cv);
+    launch_word_embed(pooled, word_w, word_b, lvl_pos, x_out, B, lq, C, Cv, (hipStream_t)stream);
     return vh_launch_status();
 }
 
@@ -165,7 +247,8 @@ extern "C" int varhip_quant_residual_f32(const int64_t* idx, const float* codebo
     VhScope sc(VH_FAM_OTHER, (hipStream_t)stream, 2.0 * tot * 9 * Cv, 24.0 * tot);
     const unsigned blocks = (unsigned)((tot + 255) / 256);
     hipLaunchKernelGGL(k_gather_up<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, idx, codebook, tap_idx, tap_w, up, B, pn, P, Cv);
-    hipLaunchKernelGGL(k_phi_accum_rest, dim3(blocks), dim3(256), 0, (hipStream_t)stream, up, phi_w, phi_b, ratio, 1.0f - ratio, f_hat, f_rest, B, P, Cv);
+    if (!launch_phi_accum(up, phi_w, phi_b, ratio, f_hat, f_rest, B, P, Cv, (hipStream_t)stream))
+        hipLaunchKernelGGL(k_phi_accum_rest, dim3(blocks), dim3(256), 0, (hipStream_t)stream, up, phi_w, phi_b, ratio, 1.0f - ratio, f_hat, f_rest, B, P, Cv);
     return vh_launch_status();
 }
 

@@ -94,12 +94,20 @@ __global__ void __launch_bounds__(256) k_cfg_sample(const float* __restrict__ lo
         // ... so that the ascending walk with the fp64 running sum (ATen's cumsum order) is a bare add/compare per entry.
         // Masked (-inf) entries precede everything and add exactly 0; the removed set is a prefix of the order (cum is
         // non-decreasing); the last (largest) entry is never removed.
+        // (entries are fetched eight at a time so the LDS latency is paid once per batch, not once per add)
         if (tid == 0) {
             double c = 0.0;
-            for (int sidx = 0; sidx < cnt - 1; ++sidx) {
-                const unsigned long long e = srt[sidx];
-                c += (double)__uint_as_float((unsigned)(e >> 32));
-                if ((float)c <= thr) xs[(unsigned)e] = -INFINITY; else break;
+            bool done = false;
+            for (int s0 = 0; s0 < cnt - 1 && !done; s0 += 8) {
+                unsigned long long e[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) e[j] = srt[s0 + j < cnt ? s0 + j : cnt - 1];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (done || s0 + j >= cnt - 1) continue;
+                    c += (double)__uint_as_float((unsigned)(e[j] >> 32));
+                    if ((float)c <= thr) xs[(unsigned)e[j]] = -INFINITY; else done = true;
+                }
             }
         }
         __syncthreads();
