@@ -116,6 +116,7 @@ __global__ void __launch_bounds__(256) k_attn_cached(const float* __restrict__ q
     for (int kt = 0; kt < ntile; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < ntile) { stage_k(kt + 1, buf ^ 1); stage_v(kt + 1, buf ^ 1); }
+        if (t0 >= l) { __syncthreads(); continue; }               // ragged last workgroup: a wave without queries only stages and syncs
         f32x16 p;
         scores(buf, kt, p);
         float tmax = p[0];

@@ -52,6 +52,17 @@ __global__ void __launch_bounds__(256) k_ln_modulate(const float* __restrict__ x
             else { v[t][0] = v[t][1] = v[t][2] = v[t][3] = 0.f; }
         }
     }
+    // the modulation vectors do not depend on the statistics: fetch them now so their latency hides under the two reductions
+    const float* sc = scale + (int64_t)(m / rows_per_group) * lds_;
+    const float* sh = shift + (int64_t)(m / rows_per_group) * ldh;
+    f32x4 s4[LN_MAXV], h4[LN_MAXV];
+#pragma unroll
+    for (int t = 0; t < LN_MAXV; ++t) {
+        if (t < nv) {
+            const int i = 256 * t + 4 * lane;
+            if (i < C) { s4[t] = *(const f32x4*)(sc + i); h4[t] = *(const f32x4*)(sh + i); }
+        }
+    }
     const float mean = vh_wave_sum(part) / (float)C;
     part = 0.f;
 #pragma unroll
@@ -66,17 +77,14 @@ __global__ void __launch_bounds__(256) k_ln_modulate(const float* __restrict__ x
     }
     const float var = vh_wave_sum(part) / (float)C;
     const float rstd = 1.0f / vm_sqrt(var + eps);
-    const float* sc = scale + (int64_t)(m / rows_per_group) * lds_;
-    const float* sh = shift + (int64_t)(m / rows_per_group) * ldh;
 #pragma unroll
     for (int t = 0; t < LN_MAXV; ++t) {
         if (t < nv) {
             const int i = 256 * t + 4 * lane;
             if (i < C) {
-                const f32x4 s4 = *(const f32x4*)(sc + i), h4 = *(const f32x4*)(sh + i);
                 f32x4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (v[t][e] * rstd) * (s4[e] + 1.0f) + h4[e];
+                for (int e = 0; e < 4; ++e) o[e] = (v[t][e] * rstd) * (s4[t][e] + 1.0f) + h4[t][e];
                 *(f32x4*)(out + (int64_t)m * C + i) = o;
             }
         }
@@ -179,7 +187,18 @@ __global__ void __launch_bounds__(256) k_gn_partial(const float* __restrict__ x,
     if (prow < rpp) {
         double s[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
         const float* px = x + ((int64_t)b * HW + p0 + prow) * C + 4 * q;
-        for (int p = p0 + prow; p < p1; p += rpp, px += (int64_t)rpp * C) {
+        const int64_t step = (int64_t)rpp * C;
+        int p = p0 + prow;
+        for (; p + 3 * rpp < p1; p += 4 * rpp, px += 4 * step) {    // four loads in flight; accumulation order unchanged (ascending p)
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *(const f32x4*)(px + u * step);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const double d = (double)v[u][e]; s[e] += d; s2[e] += d * d; }
+        }
+        for (; p < p1; p += rpp, px += step) {
             const f32x4 v = *(const f32x4*)px;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const double d = (double)v[e]; s[e] += d; s2[e] += d * d; }
@@ -234,7 +253,24 @@ __global__ void __launch_bounds__(256) k_gn_apply(const float* __restrict__ x, c
     const f32x4 g4 = *(const f32x4*)(gamma + 4 * q), b4 = *(const f32x4*)(beta + 4 * q);
     const int p0 = chunk * GN_PIX, p1 = (p0 + GN_PIX < HW) ? p0 + GN_PIX : HW;
     int64_t off = ((int64_t)b * HW + p0 + prow) * C + 4 * q;
-    for (int p = p0 + prow; p < p1; p += rpp, off += (int64_t)rpp * C) {
+    const int64_t step = (int64_t)rpp * C;
+    int p = p0 + prow;
+    for (; p + 3 * rpp < p1; p += 4 * rpp, off += 4 * step) {      // four independent 16-byte loads in flight per thread
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *(const f32x4*)(x + off + u * step);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float y = ((v[u][e] - mean[e]) * rstd[e]) * g4[e] + b4[e];
+                o[e] = silu ? vm_silu(y) : y;
+            }
+            *(f32x4*)(out + off + u * step) = o;
+        }
+    }
+    for (; p < p1; p += rpp, off += step) {
         const f32x4 v = *(const f32x4*)(x + off);
         f32x4 o;
 #pragma unroll
