@@ -24,7 +24,7 @@ __device__ __forceinline__ void swap_pair(f32x16& p) {      // registers (E, E+1
     p[E + 1] = __uint_as_float(r[1]);
 }
 
-__global__ void __launch_bounds__(256) k_attn_cached(const float* __restrict__ q, const float* __restrict__ kcache, const float* __restrict__ vcache,
+__global__ void __launch_bounds__(256, 4) k_attn_cached(const float* __restrict__ q, const float* __restrict__ kcache, const float* __restrict__ vcache,
                                                      float* __restrict__ out, int l, int H, int curL, int Lmax) {
     // one LDS array: K stages | V stages; the Q staging at the start and the O transpose at the end alias it
     __shared__ __attribute__((aligned(16))) float smem[2 * 32 * KLD + 2 * 32 * VLD];
