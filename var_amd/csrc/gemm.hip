@@ -70,7 +70,13 @@ __global__ void __launch_bounds__(256) k_gemm_any(GemmP p) {
 // 2x2 waves; a wave owns (TMW*16) x (TNW*16) outputs.  Two LDS stages, one barrier per K tile.
 __device__ __attribute__((aligned(128))) float g_zero_row[32];      // source of the zero padding taps of the convolution (never written)
 
-template <int TMW, int TNW, bool CONV>
+template <int N> __device__ __forceinline__ void vh_waitcnt_barrier() { asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory"); }
+template <int MAXA, int PER> __device__ __forceinline__ void vh_wait_dma_and_barrier(int ahead) {      // `ahead` is wave-uniform
+    if constexpr (MAXA == 0) vh_waitcnt_barrier<0>();
+    else { if (ahead >= MAXA) vh_waitcnt_barrier<MAXA * PER>(); else vh_wait_dma_and_barrier<MAXA - 1, PER>(ahead); }
+}
+
+template <int TMW, int TNW, bool CONV, int NST = 2>
 __global__ void __launch_bounds__(256) k_dma_gemm(GemmP p) {
     constexpr int BK = 32, BM = TMW * 32, BN = TNW * 32, STAGE = (BM + BN) * BK;
     constexpr int NIA = BM / 32, NIB = BN / 32;                   // DMA instructions per wave and K tile
@@ -154,13 +160,19 @@ __global__ void __launch_bounds__(256) k_dma_gemm(GemmP p) {
 
     const int r16 = lane & 15, kq = lane >> 4;
     const int nk = p.K / BK;
-    dma_tile(0, 0);
-    __syncthreads();                                              // includes the wait for this wave's own DMA (vmcnt)
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) dma_tile(kt + 1, cur ^ 1);               // stage cur^1 was last read before the previous barrier
+    auto compute = [&](int cur) {
         const float* sA = smem + cur * STAGE + (wm * TMW * 16 + r16) * BK + kq;
         const float* sB = smem + cur * STAGE + BM * BK + (wn * TNW * 16 + r16) * BK + kq;
+        if constexpr (TMW * TNW == 1) {
+            // one accumulator per wave: the MFMAs form a dependent chain and a step would otherwise wait one LDS round trip;
+            // fetch the fragments of all eight steps first
+            float a8[8], b8[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) { const int sl = (s ^ (r16 & 7)) << 2; a8[s] = sA[sl]; b8[s] = sB[sl]; }
+#pragma unroll
+            for (int s = 0; s < 8; ++s) acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b8[s], a8[s], acc[0][0], 0, 0, 0);
+            return;
+        }
         // operand fragments of step s+1 are read while the MFMAs of step s run (two register sets; the scheduling barrier keeps
         // the compiler from sinking the reads back next to their use): +2..3 % on the 128-wide tiles, neutral on 64x64
         float am[2][TMW], bn[2][TNW];
@@ -186,7 +198,32 @@ __global__ void __launch_bounds__(256) k_dma_gemm(GemmP p) {
                 for (int j = 0; j < TNW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bn[s & 1][j], am[s & 1][i], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();
+    };
+    if constexpr (NST == 2) {
+        dma_tile(0, 0);
+        __syncthreads();                                          // includes the wait for this wave's own DMA (vmcnt)
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) dma_tile(kt + 1, cur ^ 1);           // stage cur^1 was last read before the previous barrier
+            compute(cur);
+            __syncthreads();
+        }
+    } else {
+        // Deep pipeline for launches with fewer workgroups than CUs (small scales): NST-1 tiles in flight, so the K loop of the
+        // lone workgroup on a CU runs at the DMA issue rate, not at one memory latency per tile.  LDS-DMA completes in order per
+        // wave: waiting until at most `ahead` later tiles are outstanding means tile kt has landed; the barrier then publishes all
+        // four waves' parts and doubles as the "stage (kt-1) % NST is free" signal for the next issue.  (A __syncthreads() would
+        // drain every DMA.)
+        constexpr int PER = NIA + NIB;
+        static_assert((NST - 2) * PER <= 63, "vmcnt is a 6-bit counter");
+#pragma unroll
+        for (int t = 0; t < NST - 1; ++t) if (t < nk) dma_tile(t, t);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int ahead = (nk - 1 - kt) < (NST - 2) ? (nk - 1 - kt) : (NST - 2);
+            vh_wait_dma_and_barrier<NST - 2, PER>(ahead);
+            if (kt + NST - 1 < nk) dma_tile(kt + NST - 1, (kt + NST - 1) % NST);
+            compute(kt % NST);
+        }
     }
 
     // ---- epilogue: acc[i][j][e] = C[m = tile_m(i) + r16][n = tile_n(j) + 4*kq + e]
@@ -293,12 +330,12 @@ __global__ void __launch_bounds__(256) k_dma_gemm(GemmP p) {
     }
 }
 
-template <int TMW, int TNW, bool CONV = false>
+template <int TMW, int TNW, bool CONV = false, int NST = 2>
 static int launch_dma(GemmP& p, int batch, hipStream_t stream) {
     constexpr int BM = TMW * 32, BN = TNW * 32;
-    constexpr size_t lds = 2 * (size_t)(BM + BN) * 32 * sizeof(float);
+    constexpr size_t lds = NST * (size_t)(BM + BN) * 32 * sizeof(float);
     p.tilesM = (p.M + BM - 1) / BM; p.tilesN = (p.N + BN - 1) / BN;
-    auto kfn = k_dma_gemm<TMW, TNW, CONV>;
+    auto kfn = k_dma_gemm<TMW, TNW, CONV, NST>;
     static bool attr_done = false;
     if (!attr_done) {
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -337,13 +374,20 @@ extern "C" int varhip_gemm_nt_f32(const float* A, int64_t lda, const float* W, i
         return (double)((nb + 255) / 256) * bm * bn / eff;
     };
     const double c128 = cost(128, 128, 1.0), c12864 = cost(128, 64, 0.97), c64 = cost(64, 64, 0.93);
-    const int pick = !vec ? 3 : (c128 <= c12864 && c128 <= c64) ? 0 : (c12864 <= c64 ? 1 : 2);
+    int pick = !vec ? 3 : (c128 <= c12864 && c128 <= c64) ? 0 : (c12864 <= c64 ? 1 : 2);
+    static const int forced = [] { const char* e = getenv("VARHIP_GEMM_TILE"); return e ? atoi(e) : -1; }();   // experiments only
+    // fewer 64x64 tiles than half the CUs (the l = 1 and l = 4 scales): the lone workgroup of a CU is bound by one LDS round trip
+    // per k-step and one memory latency per K tile, so 32x32 tiles (4x the workgroups) with 7 tiles of DMA in flight win
+    if (pick == 2 && (int64_t)((M + 63) / 64) * ((N + 63) / 64) * batch <= 128) pick = 4;
+    if (vec && forced >= 0 && forced <= 2) pick = forced;
+    if (vec && forced == 3) pick = 4;
     VhScope scope(pick == 0 ? VH_FAM_GEMM : VH_FAM_GEMM_SMALL, (hipStream_t)stream, 2.0 * M * N * (double)K * batch,
                   4.0 * batch * ((double)M * K + (double)N * K + (double)M * N));
     switch (pick) {
         case 0: return launch_dma<4, 4>(p, batch, (hipStream_t)stream);
         case 1: return launch_dma<4, 2>(p, batch, (hipStream_t)stream);
         case 2: return launch_dma<2, 2>(p, batch, (hipStream_t)stream);
+        case 4: return launch_dma<1, 1, false, 8>(p, batch, (hipStream_t)stream);
         default: return launch_any(p, batch, (hipStream_t)stream);                 // any K / alignment: scalar guarded loads
     }
 }
