@@ -202,6 +202,32 @@ def test_cfg_sample_exact(B, l, V, t, top_k, top_p, scale):
     check('sampler tokens', gi, wi)
 
 
+@pytest.mark.parametrize('V,top_k,top_p,n_above,n_tie', [(4096, 900, 0.96, 500, 2000), (4096, 900, 0.3, 899, 3197), (4096, 900, 0.96, 0, 4096),
+                                                         (768, 0, 0.9, 0, 0), (4096, 100, 0.999, 99, 300)])
+def test_cfg_sample_tie_crowd_beyond_sort_buffer(V, top_k, top_p, n_above, n_tie):
+    """more exact ties with the k-th value than the kernel's sort buffer holds (cap = pow2 >= top_k): the tie group is walked in
+    index order unsorted.  Also a vocabulary that is not a power of two.  t = 0, unconditional half zero: x == cond exactly."""
+    rng = np.random.default_rng(V + n_tie)
+    B, l = 2, 3
+    lg = rnd(rng, B * l, V, scale=2.0)
+    if n_tie:
+        for r in range(B * l):
+            perm = rng.permutation(V)
+            lg[r, perm[:n_above]] = np.abs(lg[r, perm[:n_above]]) + 1.5          # strictly above the tie value
+            lg[r, perm[n_above:n_above + n_tie]] = 1.25                           # the crowd
+            rest = perm[n_above + n_tie:]
+            lg[r, rest] = -np.abs(lg[r, rest]) - 0.5
+    two = np.concatenate([lg, np.zeros_like(lg)], 0)
+    noise = rng.exponential(1.0, (B * l, V)).astype(np.float32)
+    idx = np.zeros(B * l, np.int64); masked = np.zeros((B * l, V), np.float32)
+    (gi, gm), (wi, wm) = both('cfg_sample_f32', [two, noise, idx, masked, B, l, V, 0.0, top_k, top_p], [2, 3])
+    check('tie crowd kept-set', np.isfinite(gm), np.isfinite(wm))
+    check('tie crowd masked logits', gm, wm)
+    check('tie crowd tokens', gi, wi)
+    if n_tie:
+        assert np.isfinite(wm).sum(axis=1).min() >= 1
+
+
 def test_cfg_sample_ties_and_golden(golden_dir):
     """rows full of exact ties, and the reference's own sampler fixtures (tests/golden/sampler.npz) straight through the HIP kernel"""
     import json

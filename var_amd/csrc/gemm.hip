@@ -398,7 +398,7 @@ static int launch_conv(GemmP& p, int batch, hipStream_t s) {
     if (p.N % 160 == 0) return launch_dma<4, 5, true>(p, batch, s);
     if (p.N % 128 == 0) return launch_dma<4, 4, true>(p, batch, s);
     if (p.N % 64 == 0) return launch_dma<4, 2, true>(p, batch, s);
-    return launch_dma<4, 1, true>(p, batch, s);
+    return launch_dma<4, 1, true>(p, batch, s);         // (a 4-stage pipeline was measured here: slower, occupancy matters more)
 }
 
 // ---- mat_qkv with the q/k/v post-processing in the epilogue (basic_var.py:93-109): the [M][3C] intermediate never reaches HBM.

@@ -13,10 +13,10 @@ __device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int
 
 __global__ void __launch_bounds__(256) k_cfg_sample(const float* __restrict__ logits, const float* __restrict__ noise, int64_t* __restrict__ idx_out,
                                                     float* __restrict__ masked_out, int64_t rows, int V, float ca, float cb,
-                                                    int top_k, int use_top_p, float thr) {
+                                                    int top_k, int use_top_p, float thr, int cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm_raw[];
     float* xs = reinterpret_cast<float*>(sm_raw);                                   // [V] working logits
-    unsigned long long* srt = reinterpret_cast<unsigned long long*>(sm_raw + sizeof(float) * V);   // [V] (key<<32 | idx)
+    unsigned long long* srt = reinterpret_cast<unsigned long long*>(sm_raw + sizeof(float) * V);   // [cap] (key<<32 | idx), cap = pow2 >= top_k (or V)
     __shared__ int s_ci[8];
     __shared__ float red[4];
     __shared__ unsigned s_cnt;
@@ -33,8 +33,8 @@ __global__ void __launch_bounds__(256) k_cfg_sample(const float* __restrict__ lo
 
     // (2) top-k: the key of the k-th largest, built bit by bit from the top: T is the largest value with count(key >= T) >= k.
     // 32 exact integer block reductions, no atomics (a radix histogram serialises on the few populated top-byte bins).
+    unsigned T = 0u;                                   // key of the k-th largest (0: no top-k, every key is >= it)
     if (top_k > 0) {
-        unsigned T = 0u;
         for (int bit = 31; bit >= 0; --bit) {
             const unsigned cand = T | (1u << bit);
             int cnt = 0;
@@ -58,14 +58,24 @@ __global__ void __launch_bounds__(256) k_cfg_sample(const float* __restrict__ lo
     // (3) top-p
     if (use_top_p) {
         float part = 0.f;
-        for (int i = tid; i < V; i += 256) part = part + vm_exp(xs[i] - m);
+        int fin = 0;
+        for (int i = tid; i < V; i += 256) { part = part + vm_exp(xs[i] - m); fin += (xs[i] > -INFINITY) ? 1 : 0; }
         const float S = vh_block_sum256(part, red);
-        // compact the finite entries (order irrelevant: they get sorted), pad to a power of two with +max keys
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) fin += __shfl_xor(fin, off, 64);
+        if ((tid & 63) == 0) s_ci[tid >> 6] = fin;
         if (tid == 0) s_cnt = 0u;
         __syncthreads();
+        const int total = s_ci[0] + s_ci[1] + s_ci[2] + s_ci[3];      // survivors of top-k (ties with the k-th value included)
+        // The sort buffer holds `cap` entries (a power of two >= top_k, so that more workgroups fit a CU).  Only a crowd of exact
+        // ties with the k-th value can exceed it; those ties are the SMALLEST survivors and sort among themselves by index, so
+        // they need no sorting: in that case only the entries strictly above the k-th value (< top_k of them) are sorted and the
+        // tie group is walked in index order first.
+        const bool split = total > cap;
+        // compact (order irrelevant: they get sorted), pad to a power of two with +max keys
         for (int i = tid; i < V; i += 256) {
             const float v = xs[i];
-            if (v > -INFINITY) { const unsigned pos = atomicAdd(&s_cnt, 1u); srt[pos] = ((unsigned long long)vm_float_key(v) << 32) | (unsigned)i; }
+            if (v > -INFINITY && (!split || vm_float_key(v) > T)) { const unsigned pos = atomicAdd(&s_cnt, 1u); srt[pos] = ((unsigned long long)vm_float_key(v) << 32) | (unsigned)i; }
         }
         __syncthreads();
         const int cnt = (int)s_cnt;
@@ -85,7 +95,7 @@ __global__ void __launch_bounds__(256) k_cfg_sample(const float* __restrict__ lo
                 __syncthreads();
             }
         }
-        // every survivor's probability, in sorted order, replaces the (now useless) key half of its sort entry ...
+        // every sorted survivor's probability replaces the (now useless) key half of its sort entry ...
         for (int sidx = tid; sidx < cnt; sidx += 256) {
             const unsigned i = (unsigned)srt[sidx];
             srt[sidx] = ((unsigned long long)__float_as_uint(vm_exp(xs[i] - m) / S) << 32) | i;
@@ -98,15 +108,26 @@ __global__ void __launch_bounds__(256) k_cfg_sample(const float* __restrict__ lo
         if (tid == 0) {
             double c = 0.0;
             bool done = false;
-            for (int s0 = 0; s0 < cnt - 1 && !done; s0 += 8) {
+            int left = total - 1;                                   // entries that may still be removed
+            if (split) {                                            // tie group first, ascending index; all share one probability
+                float pT = 0.f;
+                for (int i = 0; i < V && left > 0 && !done; ++i) {
+                    const float v = xs[i];
+                    if (!(v > -INFINITY) || vm_float_key(v) != T) continue;
+                    pT = vm_exp(v - m) / S;
+                    c += (double)pT;
+                    if ((float)c <= thr) { xs[i] = -INFINITY; --left; } else done = true;
+                }
+            }
+            for (int s0 = 0; s0 < cnt && left > 0 && !done; s0 += 8) {
                 unsigned long long e[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) e[j] = srt[s0 + j < cnt ? s0 + j : cnt - 1];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    if (done || s0 + j >= cnt - 1) continue;
+                    if (done || left <= 0 || s0 + j >= cnt) continue;
                     c += (double)__uint_as_float((unsigned)(e[j] >> 32));
-                    if ((float)c <= thr) xs[(unsigned)e[j]] = -INFINITY; else done = true;
+                    if ((float)c <= thr) { xs[(unsigned)e[j]] = -INFINITY; --left; } else done = true;
                 }
             }
         }
@@ -152,12 +173,13 @@ extern "C" int varhip_cfg_sample_f32(const float* logits, const float* noise, in
                                      int B, int l, int V, double t_cfg, int top_k, double top_p, varhip_stream_t stream) {
     if (B <= 0 || l <= 0 || V <= 0 || (V & 255) || V > 8192 || top_k < 0 || top_k > V) return VARHIP_EINVAL;
     const int64_t rows = (int64_t)B * l;
-    const size_t lds = (sizeof(float) + sizeof(unsigned long long)) * (size_t)V;
+    int cap = 2; while (cap < (top_k > 0 ? top_k : V)) cap <<= 1;       // sort buffer entries (see the kernel: ties beyond it are handled unsorted)
+    const size_t lds = sizeof(float) * (size_t)V + sizeof(unsigned long long) * (size_t)cap;
     static bool attr_done = false;
     if (!attr_done) { (void)hipFuncSetAttribute((const void*)k_cfg_sample, hipFuncAttributeMaxDynamicSharedMemorySize, 12 * 8192); attr_done = true; }
     VhScope sc(VH_FAM_SAMPLER, (hipStream_t)stream, 0, 4.0 * rows * V * 3.0);
     hipLaunchKernelGGL(k_cfg_sample, dim3((unsigned)rows), dim3(256), lds, (hipStream_t)stream, logits, noise, idx_out, masked_out, rows, V,
-                       (float)(1.0 + t_cfg), (float)t_cfg, top_k, top_p > 0.0 ? 1 : 0, (float)(1.0 - top_p));
+                       (float)(1.0 + t_cfg), (float)t_cfg, top_k, top_p > 0.0 ? 1 : 0, (float)(1.0 - top_p), cap);
     return vh_launch_status();
 }
 
