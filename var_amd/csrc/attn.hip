@@ -16,6 +16,9 @@
 #define KLD 68          // K tile row stride (floats): 64 + 4 -> conflict-free ds_read_b128 / ds_write_b128
 #define VLD 64
 #define OLD 65
+#ifndef ATTN_WG_PER_CU
+#define ATTN_WG_PER_CU 4      // workgroups per CU the register allocation is capped for
+#endif
 
 template <int E>
 __device__ __forceinline__ void swap_pair(f32x16& p) {      // registers (E, E+1): afterwards E = keys (2s,2s+1), E+1 = keys (2s+4, 2s+5)
@@ -24,7 +27,7 @@ __device__ __forceinline__ void swap_pair(f32x16& p) {      // registers (E, E+1
     p[E + 1] = __uint_as_float(r[1]);
 }
 
-__global__ void __launch_bounds__(256, 4) k_attn_cached(const float* __restrict__ q, const float* __restrict__ kcache, const float* __restrict__ vcache,
+__global__ void __launch_bounds__(256, ATTN_WG_PER_CU) k_attn_cached(const float* __restrict__ q, const float* __restrict__ kcache, const float* __restrict__ vcache,
                                                      float* __restrict__ out, int l, int H, int curL, int Lmax) {
     // one LDS array: K stages | V stages; the Q staging at the start and the O transpose at the end alias it
     __shared__ __attribute__((aligned(16))) float smem[2 * 32 * KLD + 2 * 32 * VLD];
@@ -71,20 +74,23 @@ __global__ void __launch_bounds__(256, 4) k_attn_cached(const float* __restrict_
         __syncthreads();
     }
 
-    auto stage_k = [&](int kt, int buf) {
+    // K/V tile staging, split so the global loads of tile kt+1 are in flight during the math of tile kt and only meet their
+    // LDS stores at the end of the tile (a fused load->store waits a full memory latency at the top of every tile)
+    f32x4 gk0 = zero4, gk1 = zero4, gv0 = zero4, gv1 = zero4;
+    auto load_kv = [&](int kt) {
         const int key = kt * 32 + sr;
-        f32x4 a = zero4, bq = zero4;
-        if (key < curL) { const float* s = Kc + (int64_t)key * 64 + sc * 8; a = *(const f32x4*)s; bq = *(const f32x4*)(s + 4); }
-        float* d = &sK[buf][sr * KLD + sc * 8];
-        const f32x4 ev = {a[0], a[2], bq[0], bq[2]}, od = {a[1], a[3], bq[1], bq[3]};
-        *(f32x4*)d = ev; *(f32x4*)(d + 4) = od;
+        gk0 = zero4; gk1 = zero4; gv0 = zero4; gv1 = zero4;
+        if (key < curL) {
+            const float* sk = Kc + (int64_t)key * 64 + sc * 8; gk0 = *(const f32x4*)sk; gk1 = *(const f32x4*)(sk + 4);
+            const float* sv = Vc + (int64_t)key * 64 + sc * 8; gv0 = *(const f32x4*)sv; gv1 = *(const f32x4*)(sv + 4);
+        }
     };
-    auto stage_v = [&](int kt, int buf) {
-        const int key = kt * 32 + sr;
-        f32x4 a = zero4, bq = zero4;
-        if (key < curL) { const float* s = Vc + (int64_t)key * 64 + sc * 8; a = *(const f32x4*)s; bq = *(const f32x4*)(s + 4); }
-        float* d = &sV[buf][sr * VLD + sc * 8];
-        *(f32x4*)d = a; *(f32x4*)(d + 4) = bq;
+    auto store_kv = [&](int buf) {
+        float* dk = &sK[buf][sr * KLD + sc * 8];
+        const f32x4 ev = {gk0[0], gk0[2], gk1[0], gk1[2]}, od = {gk0[1], gk0[3], gk1[1], gk1[3]};    // even k first, then odd k (see gemm notes)
+        *(f32x4*)dk = ev; *(f32x4*)(dk + 4) = od;
+        float* dv = &sV[buf][sr * VLD + sc * 8];
+        *(f32x4*)dv = gv0; *(f32x4*)(dv + 4) = gv1;
     };
     auto scores = [&](int buf, int kt, f32x16& acc) {              // S^T tile: rows = keys, col (lane) = query
 #pragma unroll
@@ -111,12 +117,12 @@ __global__ void __launch_bounds__(256, 4) k_attn_cached(const float* __restrict_
 #pragma unroll
     for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; }
     float lsum = 0.f, mx = -INFINITY;
-    stage_k(0, 0); stage_v(0, 0);
+    load_kv(0); store_kv(0);
     __syncthreads();
     for (int kt = 0; kt < ntile; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < ntile) { stage_k(kt + 1, buf ^ 1); stage_v(kt + 1, buf ^ 1); }
-        if (t0 >= l) { __syncthreads(); continue; }               // ragged last workgroup: a wave without queries only stages and syncs
+        if (kt + 1 < ntile) load_kv(kt + 1);
+        if (t0 >= l) { if (kt + 1 < ntile) store_kv(buf ^ 1); __syncthreads(); continue; }   // ragged last workgroup: a wave without queries only stages and syncs
         f32x16 p;
         scores(buf, kt, p);
         float tmax = p[0];
@@ -148,6 +154,7 @@ __global__ void __launch_bounds__(256, 4) k_attn_cached(const float* __restrict_
                 o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, pv, o1, 0, 0, 0);
             }
         }
+        if (kt + 1 < ntile) store_kv(buf ^ 1);                     // stage buf^1 was last read before the previous barrier
         __syncthreads();
     }
     const float ltot = lsum + __shfl_xor(lsum, 32, 64);
