@@ -145,7 +145,9 @@ int varhip_first_map_f32(const float* class_emb, const int64_t* labels, int num_
  *             (vqvae.py:63 clamp_ and var.py:190 add_(1).mul_(0.5) fused into the last conv);
  *   out_mode 2: [B][Cout][H][W] holding clamp(v,-1,1) only (VQVAE.fhat_to_img's own contract)
  * replaces every Conv2d(k=3) of basic_vae.py (ResnetBlock :48,:51; conv_in :180; conv_out :208; Upsample2x :25)
- * and vqvae.py:49 post_quant_conv.   Constraint: Cin % 32 == 0 (a K tile of the implicit GEMM lies inside one tap). */
+ * and vqvae.py:49 post_quant_conv.   Constraint: Cin % 32 == 0 (a K tile of the implicit GEMM lies inside one tap).
+ * Summation order (arithmetic contract of every 3x3 convolution here): one fma chain per output over 32-channel chunks
+ * (outermost), then the taps (ky, kx), then the channels of the chunk. */
 int varhip_conv3x3_nhwc_f32(const float* in, const float* w, const float* bias, const float* resid, float* out,
                             int B, int H, int W, int Cin, int Cout, int up2, int out_mode, varhip_stream_t stream);
 

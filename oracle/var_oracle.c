@@ -524,18 +524,24 @@ static void conv3x3_core(const float* in, const float* wt, const float* bias, co
             float* acc = (float*)malloc(sizeof(float) * Cout);
             for (int x = 0; x < W; ++x) {
                 for (int co = 0; co < Cout; ++co) acc[co] = 0.0f;
-                for (int ky = 0; ky < 3; ++ky) {
-                    int yy = up2 == 3 ? 2 * y + ky : y + ky - 1; if (yy < 0 || yy >= (up2 == 3 ? Hi : H)) continue;
-                    for (int kx = 0; kx < 3; ++kx) {
-                        int xx = up2 == 3 ? 2 * x + kx : x + kx - 1; if (xx < 0 || xx >= (up2 == 3 ? Wi : W)) continue;
-                        int sy = up2 == 1 ? yy >> 1 : yy, sx = up2 == 1 ? xx >> 1 : xx;     /* nearest 2x: src = dst // 2 */
-                        const float* ip = in + (((int64_t)b * Hi + sy) * Wi + sx) * Cin;
-                        const float* wp = wt + ((int64_t)(ky * 3 + kx) * Cin) * Cout;
-                        for (int ci = 0; ci < Cin; ++ci) {
-                            float a = ip[ci];
-                            const float* wr = wp + (int64_t)ci * Cout;
+                /* summation order of the contract (include/var_hip.h): channel chunks of 32 outermost, then the 9 taps, then the
+                 * channels of the chunk — all taps of a chunk touch the same few cache lines, which is what keeps the GPU kernel's
+                 * operand re-reads inside the L2 */
+                for (int c0 = 0; c0 < Cin; c0 += 32) {
+                    int c1 = c0 + 32 < Cin ? c0 + 32 : Cin;
+                    for (int ky = 0; ky < 3; ++ky) {
+                        int yy = up2 == 3 ? 2 * y + ky : y + ky - 1; if (yy < 0 || yy >= (up2 == 3 ? Hi : H)) continue;
+                        for (int kx = 0; kx < 3; ++kx) {
+                            int xx = up2 == 3 ? 2 * x + kx : x + kx - 1; if (xx < 0 || xx >= (up2 == 3 ? Wi : W)) continue;
+                            int sy = up2 == 1 ? yy >> 1 : yy, sx = up2 == 1 ? xx >> 1 : xx;     /* nearest 2x: src = dst // 2 */
+                            const float* ip = in + (((int64_t)b * Hi + sy) * Wi + sx) * Cin;
+                            const float* wp = wt + ((int64_t)(ky * 3 + kx) * Cin) * Cout;
+                            for (int ci = c0; ci < c1; ++ci) {
+                                float a = ip[ci];
+                                const float* wr = wp + (int64_t)ci * Cout;
 #pragma omp simd
-                            for (int co = 0; co < Cout; ++co) acc[co] = vm_fma(a, wr[co], acc[co]);
+                                for (int co = 0; co < Cout; ++co) acc[co] = vm_fma(a, wr[co], acc[co]);
+                            }
                         }
                     }
                 }
@@ -612,13 +618,16 @@ int varref_upconv_phase_f32(const float* in, const float* wp, const float* bias,
                 const int y = Y >> 1, py = Y & 1, x = X >> 1, px = X & 1, ph = 2 * py + px;
                 for (int co = 0; co < Cout; ++co) {
                     float acc = 0.0f;
-                    for (int a = 0; a < 2; ++a) {
-                        int yy = y + a - 1 + py; if (yy < 0 || yy >= Hl) continue;
-                        for (int bb = 0; bb < 2; ++bb) {
-                            int xx = x + bb - 1 + px; if (xx < 0 || xx >= Wl) continue;
-                            const float* ip = in + (((int64_t)b * Hl + yy) * Wl + xx) * Cin;
-                            const float* w = wp + ((((int64_t)ph * Cout + co) * 2 + a) * 2 + bb) * Cin;
-                            for (int ci = 0; ci < Cin; ++ci) acc = vm_fma(ip[ci], w[ci], acc);
+                    for (int c0 = 0; c0 < Cin; c0 += 32) {                /* same order as conv3x3_core: chunk, tap, channel */
+                        int c1 = c0 + 32 < Cin ? c0 + 32 : Cin;
+                        for (int a = 0; a < 2; ++a) {
+                            int yy = y + a - 1 + py; if (yy < 0 || yy >= Hl) continue;
+                            for (int bb = 0; bb < 2; ++bb) {
+                                int xx = x + bb - 1 + px; if (xx < 0 || xx >= Wl) continue;
+                                const float* ip = in + (((int64_t)b * Hl + yy) * Wl + xx) * Cin;
+                                const float* w = wp + ((((int64_t)ph * Cout + co) * 2 + a) * 2 + bb) * Cin;
+                                for (int ci = c0; ci < c1; ++ci) acc = vm_fma(ip[ci], w[ci], acc);
+                            }
                         }
                     }
                     out[(((int64_t)b * H + Y) * W + X) * Cout + co] = acc + bias[co];

@@ -107,6 +107,30 @@ def test_d16_full_pyramid_vs_reference():
     _compare('d16_full', with_oracle=False, logit_atol=1e-3)
 
 
+def test_demo_sample_calling_convention():
+    """The reference's harness (demo_sample.py:43-68) calls the model inside inference_mode + fp16 autocast with 8 labels,
+    cfg=4, top_k=900, top_p=0.95: the HIP path computes in fp32 regardless, so the enclosing autocast must not change a bit;
+    VAR.forward (teacher forcing, eval_prob.py:420-446) under the same contexts likewise."""
+    z, meta = util.load_case('t_pn12345')
+    vae, var = build_models(meta)
+    labels = torch.tensor((980, 980, 437, 437, 22, 22, 562, 562), device='cuda')
+    B = labels.numel()
+    with torch.inference_mode():
+        with torch.autocast('cuda', enabled=True, dtype=torch.float16, cache_enabled=True):
+            a = var.autoregressive_infer_cfg(B=B, label_B=labels, cfg=4, top_k=900, top_p=0.95, g_seed=0, more_smooth=False)
+        b = var.autoregressive_infer_cfg(B=B, label_B=labels, cfg=4, top_k=900, top_p=0.95, g_seed=0, more_smooth=False)
+    P = 16 * meta['patch_nums'][-1]
+    assert a.shape == (B, 3, P, P) and a.dtype == torch.float32 and float(a.min()) >= 0.0 and float(a.max()) <= 1.0
+    assert torch.equal(a, b), 'an enclosing autocast context changed the result'
+    var.cond_drop_rate = 0.0                                  # VAR.forward drops labels at random otherwise (var.py:200), also in eval
+    x = torch.randn(B, var.L - var.first_l, var.Cvae, device='cuda')
+    with torch.inference_mode():
+        with torch.autocast('cuda', enabled=True, dtype=torch.float16):
+            l1 = var(labels, x)
+        l2 = var(labels, x)
+    assert l1.dtype == torch.float32 and torch.equal(l1, l2)
+
+
 def test_public_api_and_properties():
     """VAR.autoregressive_infer_cfg with the device generator: determinism, output contract, and batch-slice invariance
     under injected noise (images are independent: SURVEY.md §8e), on the d16 (1,2,3) model."""

@@ -124,10 +124,16 @@ __global__ void __launch_bounds__(256) k_dma_gemm(GemmP p) {
     auto dma_tile = [&](int kt, int st) {
         float* sA = smem + st * STAGE + wave * (BM / 4) * BK;
         float* sB = smem + st * STAGE + BM * BK + wave * (BN / 4) * BK;
-        int dy = 0, dx = 0, ci0 = 0;
-        if (CONV) {                                               // K index = tap * Cin + ci: the tile lies inside one tap (Cin % 32 == 0)
-            const int k0 = kt * BK, tap = k0 / p.Cin;
-            ci0 = k0 - tap * p.Cin;
+        int dy = 0, dx = 0, ci0 = 0, woff = kt * BK;
+        if (CONV) {
+            // Summation order of the convolutions: 32-channel chunks outermost, then the taps, then the channels of the chunk
+            // (K tile kt = chunk kt / ntap, tap kt % ntap).  The 9 (or 4) consecutive K tiles of a chunk read the same few cache
+            // lines of the input, so the tap re-reads stay inside the XCD's L2: tap-major order moved 6.7 GB per 256x256 launch
+            // across the fabric, this order 2.4 GB (algorithmic 1.6 GB; profiles/r01_pmc_traffic.json).  Weights keep the
+            // [Cout][tap][Cin] layout: the tile's weights are the 32 floats at tap*Cin + ci0 of every row.
+            const int ntap = p.K / p.Cin, cc = kt / ntap, tap = kt - cc * ntap;
+            ci0 = cc * BK;
+            woff = tap * p.Cin + ci0;
             if (p.up2 == 2) { dy = (tap >> 1) - 1 + (bz >> 1); dx = (tap & 1) - 1 + (bz & 1); }   // phase (bz>>1, bz&1) of the folded Upsample2x conv
             else { const int ky = tap / 3; dy = ky - (p.up2 == 3 ? 0 : 1); dx = tap - ky * 3 - (p.up2 == 3 ? 0 : 1); }
         }
@@ -148,7 +154,7 @@ __global__ void __launch_bounds__(256) k_dma_gemm(GemmP p) {
         }
 #pragma unroll
         for (int i = 0; i < NIB; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[i] + kt * BK),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[i] + woff),
                                              (__attribute__((address_space(3))) void*)(sB + i * 8 * BK), 16, 0, 0);
     };
 
