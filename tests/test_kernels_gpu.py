@@ -377,7 +377,8 @@ def test_groupnorm(B, HW, C):
     for silu in (0, 1):
         out = np.zeros_like(x)
         (go,), (wo,) = both('gn_apply_f32', [x, w, gam, bet, out, B, HW, C, 32, silu], [4])
-        check(f'gn apply silu={silu} (same stats)', go, wo)
+        # the affine part is exact; the fused SiLU uses the hardware exp2/rcp (decoder only, off the token path): ~1e-7 relative
+        check(f'gn apply silu={silu} (same stats)', go, wo, exact=not silu, atol=2e-6, rtol=2e-6)
 
 
 def test_softmax_rows_exact():
