@@ -66,7 +66,7 @@ def test_library_loads_and_reports_version():
     assert torch.cuda.is_available()
 
 
-@pytest.mark.parametrize('M,N,K', [(128, 128, 128), (4, 384, 128), (36, 512, 128), (300, 320, 640), (1152, 1024, 1024), (2048, 3072, 1024), (64, 4096, 256), (1, 128, 32), (130, 40, 8), (9, 128, 9), (25, 33, 25), (70, 70, 13)])
+@pytest.mark.parametrize('M,N,K', [(128, 128, 128), (4, 384, 128), (36, 512, 128), (300, 320, 640), (1152, 1024, 1024), (2048, 3072, 1024), (64, 4096, 256), (1, 128, 32), (130, 40, 8), (9, 128, 9), (25, 33, 25), (70, 70, 13), (70, 50, 64), (3, 52, 96), (200, 17, 32)])
 @pytest.mark.parametrize('epi', [0, 1, 2])
 def test_gemm_exact(M, N, K, epi):
     rng = np.random.default_rng(M * 7 + N * 3 + K + epi)
