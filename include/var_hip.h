@@ -159,6 +159,10 @@ int varhip_conv3x3_nhwc_f32(const float* in, const float* w, const float* bias, 
 int varhip_upconv_pack_f32(const float* w, float* w_phase, int Cin, int Cout, varhip_stream_t stream);
 int varhip_upconv_phase_f32(const float* in, const float* w_phase, const float* bias, float* out,
                             int B, int H, int W, int Cin, int Cout, varhip_stream_t stream);
+/* ... and with the GroupNorm partials of its result (see varhip_conv3x3_gn_nhwc_f32): block blk = phase * ((H/2)*(W/2)/128) + t
+ * covers low-resolution pixels [128 t, 128 t + 128) of that phase */
+int varhip_upconv_phase_gn_f32(const float* in, const float* w_phase, const float* bias, float* out, double* gn_part,
+                               int B, int H, int W, int Cin, int Cout, varhip_stream_t stream);
 
 /* GroupNorm statistics: stats[b][g] = {mean, rstd} over (HW, C/G) with biased variance (basic_vae.py:18-19, eps 1e-6).
  * scratch: caller-provided, at least varhip_gn_scratch_elems(B,HW,C,G) doubles. */
@@ -177,6 +181,17 @@ int varhip_nhwc_to_nchw_f32(const float* in, float* out, int B, int C, int HW, v
 
 /* ---- encode side and teacher forcing ("next" rows of SURVEY.md §8f: image -> tokens -> teacher-forced logits) -----------------
  * Downsample2x of the encoder (basic_vae.py:31-37): F.pad(x,(0,1,0,1)) + Conv2d(k=3, stride=2): in [B][2H][2W][Cin] -> out [B][H][W][Cout] */
+/* The same convolution (out_mode 0) that also leaves GroupNorm partial sums of its result: gn_part[b][blk][co][2] (doubles) =
+ * (sum, sum of squares) over the blk-th block of 128 consecutive pixels of sample b, so the GroupNorm that follows
+ * (basic_vae.py:18-19 inside ResnetBlock / AttnBlock / norm_out) needs no statistics pass over the tensor.
+ * varhip_conv_gn_blocks(H, W, Cout, phase) = blocks per sample, or 0 when unsupported (needs H*W % 128 == 0, Cout % 32 == 0;
+ * phase != 0 describes varhip_upconv_phase_gn_f32 below: 4 * ((H/2)*(W/2) / 128) blocks, phase-major).
+ * varhip_gn_stats_part_f32 turns the partials into the (mean, rstd) pairs varhip_gn_apply_f32 takes (blocks in order, channels of
+ * a group in order, fp64). */
+int varhip_conv_gn_blocks(int H, int W, int Cout, int phase);
+int varhip_conv3x3_gn_nhwc_f32(const float* in, const float* w, const float* bias, const float* resid, float* out, double* gn_part,
+                               int B, int H, int W, int Cin, int Cout, int up2, varhip_stream_t stream);
+int varhip_gn_stats_part_f32(const double* gn_part, float* stats, int B, int nblk, int HW, int C, int G, float eps, varhip_stream_t stream);
 int varhip_conv3x3_s2_nhwc_f32(const float* in, const float* w, const float* bias, float* out,
                                int B, int H, int W, int Cin, int Cout, varhip_stream_t stream);
 /* image [B][C][HW] -> [B][HW][Cpad] with zero channels C..Cpad-1 (conv kernels need Cin % 32 == 0; zero channels add exact zeros) */

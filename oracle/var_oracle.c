@@ -636,6 +636,67 @@ int varref_upconv_phase_f32(const float* in, const float* wp, const float* bias,
     return 0;
 }
 
+/* ---- convolution that also leaves the GroupNorm partial sums of its result (a GPU-side fusion; restated here as conv followed by
+ * plain per-block sums in fp64).  gn_part[b][blk][co][2]; blocks of 128 consecutive pixels; the phase form numbers its blocks
+ * phase-major over the low-resolution pixel index (include/var_hip.h). */
+int varref_conv_gn_blocks(int H, int W, int Cout, int phase) {
+    const int hw = phase ? (H / 2) * (W / 2) : H * W;
+    if (H <= 0 || W <= 0 || Cout <= 0 || (Cout & 31) || (hw & 127) || (phase && ((H & 1) || (W & 1)))) return 0;
+    return (phase ? 4 : 1) * (hw / 128);
+}
+int varref_conv3x3_gn_nhwc_f32(const float* in, const float* w, const float* bias, const float* resid, float* out, double* gn_part,
+                               int B, int H, int W, int Cin, int Cout, int up2) {
+    const int nblk = varref_conv_gn_blocks(H, W, Cout, 0);
+    if (!nblk || !gn_part) return VARHIP_EINVAL;
+    int rc = varref_conv3x3_nhwc_f32(in, w, bias, resid, out, B, H, W, Cin, Cout, up2, 0);
+    if (rc) return rc;
+    for (int b = 0; b < B; ++b)
+        for (int k = 0; k < nblk; ++k)
+            for (int co = 0; co < Cout; ++co) {
+                double s = 0.0, q = 0.0;
+                for (int p = 0; p < 128; ++p) { double d = out[(((int64_t)b * H * W) + k * 128 + p) * Cout + co]; s += d; q += d * d; }
+                double* o = gn_part + (((int64_t)b * nblk + k) * Cout + co) * 2; o[0] = s; o[1] = q;
+            }
+    return 0;
+}
+int varref_upconv_phase_f32(const float* in, const float* wp, const float* bias, float* out, int B, int H, int W, int Cin, int Cout);
+int varref_upconv_phase_gn_f32(const float* in, const float* wp, const float* bias, float* out, double* gn_part,
+                               int B, int H, int W, int Cin, int Cout) {
+    const int nblk = varref_conv_gn_blocks(H, W, Cout, 1);
+    if (!nblk || !gn_part) return VARHIP_EINVAL;
+    int rc = varref_upconv_phase_f32(in, wp, bias, out, B, H, W, Cin, Cout);
+    if (rc) return rc;
+    const int Hl = H / 2, Wl = W / 2, per = Hl * Wl / 128;
+    for (int b = 0; b < B; ++b)
+        for (int ph = 0; ph < 4; ++ph)
+            for (int t = 0; t < per; ++t)
+                for (int co = 0; co < Cout; ++co) {
+                    double s = 0.0, q = 0.0;
+                    for (int p = 0; p < 128; ++p) {
+                        int lin = t * 128 + p, y = lin / Wl, x = lin - y * Wl;
+                        double d = out[(((int64_t)b * H + 2 * y + (ph >> 1)) * W + 2 * x + (ph & 1)) * Cout + co]; s += d; q += d * d;
+                    }
+                    double* o = gn_part + (((int64_t)b * nblk + ph * per + t) * Cout + co) * 2; o[0] = s; o[1] = q;
+                }
+    return 0;
+}
+int varref_gn_stats_part_f32(const double* part, float* stats, int B, int nblk, int HW, int C, int G, float eps) {
+    if (B <= 0 || nblk <= 0 || C <= 0 || G <= 0 || (C % G)) return VARHIP_EINVAL;
+    const int cpg = C / G;
+    const double count = (double)HW * cpg;
+    for (int b = 0; b < B; ++b)
+        for (int g = 0; g < G; ++g) {
+            double s = 0.0, s2 = 0.0;
+            for (int k = 0; k < nblk; ++k)
+                for (int c = 0; c < cpg; ++c) { const double* o = part + (((int64_t)b * nblk + k) * C + g * cpg + c) * 2; s += o[0]; s2 += o[1]; }
+            double mean = s / count, var = s2 / count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            stats[((int64_t)b * G + g) * 2] = (float)mean;
+            stats[((int64_t)b * G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        }
+    return 0;
+}
+
 int64_t varref_gn_scratch_elems(int B, int HW, int C, int G) { (void)HW; (void)C; return (int64_t)B * G * 2; }
 
 /* GroupNorm(32, C, eps=1e-6) statistics (basic_vae.py:18-19): biased variance over (HW, C/G); two-pass in double */

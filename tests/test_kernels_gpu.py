@@ -364,6 +364,50 @@ def test_upconv_phase(B, H, W, Cin, Cout):
     check('upconv phase vs 9-tap definition', g, r9, exact=False, atol=5e-5, rtol=1e-5)      # 1.9e-5 measured at K = 9*640, |out| <= 4.6
 
 
+@pytest.mark.parametrize('B,H,W,Cin,Cout,resid', [(2, 16, 16, 32, 640, 0), (2, 32, 32, 320, 320, 1), (1, 32, 64, 160, 160, 1), (3, 16, 8, 64, 64, 0), (2, 16, 16, 32, 32, 1)])
+def test_conv3x3_with_groupnorm_partials(B, H, W, Cin, Cout, resid):
+    """the conv that also leaves per-block channel sums for the GroupNorm after it: same output bits as the plain conv, partials and
+    the statistics made from them equal to the CPU twin's up to fp64 summation order, and to the stand-alone statistics kernel"""
+    L, hip = _setup()
+    rng = np.random.default_rng(H * W + Cin + Cout)
+    nblk = hip.conv_gn_blocks(H, W, Cout)
+    assert nblk == H * W // 128 and L['conv_gn_blocks'](H, W, Cout, 0) == nblk and hip.conv_gn_blocks(10, 10, Cout) == 0
+    x = rnd(rng, B, H, W, Cin); w = rnd(rng, Cout, 3, 3, Cin, scale=(1.0 / (9 * Cin)) ** 0.5); bias = rnd(rng, Cout, scale=0.1)
+    r = rnd(rng, B, H, W, Cout) if resid else None
+    out = np.zeros((B, H, W, Cout), np.float32); part = np.zeros((B, nblk, Cout, 2), np.float64)
+    (g, gp), (wv, wp) = both('conv3x3_gn_nhwc_f32', [x, w, bias, r, out, part, B, H, W, Cin, Cout, 0], [4, 5])
+    check('conv+gn output', g, wv)
+    (g0,), _ = both('conv3x3_nhwc_f32', [x, w, bias, r, np.zeros_like(out), B, H, W, Cin, Cout, 0, 0], [4])
+    check('conv+gn output vs plain conv', g, g0)
+    check('gn partials', gp, wp, exact=False, atol=1e-9, rtol=1e-12)
+    st = np.zeros((B, 32, 2), np.float32)
+    (gs,), (ws,) = both('gn_stats_part_f32', [gp, st, B, nblk, H * W, Cout, 32, 1e-6], [1])
+    check('stats from partials', gs, ws, exact=False, atol=1e-6, rtol=2e-6)
+    scratch = np.zeros(hip.gn_scratch_elems(B, H * W, Cout, 32), np.float64)
+    (g1,), _ = both('gn_stats_f32', [g, np.zeros_like(st), scratch, B, H * W, Cout, 32, 1e-6], [1])
+    check('stats from partials vs statistics kernel', gs, g1, exact=False, atol=1e-6, rtol=2e-6)
+
+
+def test_upconv_phase_with_groupnorm_partials():
+    L, hip = _setup()
+    rng = np.random.default_rng(77)
+    B, H, W, Cin, Cout = 2, 32, 32, 64, 160
+    nblk = hip.conv_gn_blocks(H, W, Cout, phase=True)
+    assert nblk == 4 * (H // 2) * (W // 2) // 128
+    x = rnd(rng, B, H // 2, W // 2, Cin); w = rnd(rng, Cout, 3, 3, Cin, scale=(1.0 / (9 * Cin)) ** 0.5); bias = rnd(rng, Cout, scale=0.1)
+    wp = np.zeros((4, Cout, 2, 2, Cin), np.float32)
+    _, (rp,) = both('upconv_pack_f32', [w, wp, Cin, Cout], [1])
+    out = np.zeros((B, H, W, Cout), np.float32); part = np.zeros((B, nblk, Cout, 2), np.float64)
+    (g, gp), (wv, wpp) = both('upconv_phase_gn_f32', [x, rp, bias, out, part, B, H, W, Cin, Cout], [3, 4])
+    check('upconv+gn output', g, wv)
+    check('upconv gn partials', gp, wpp, exact=False, atol=1e-9, rtol=1e-12)
+    st = np.zeros((B, 32, 2), np.float32)
+    (gs,), _ = both('gn_stats_part_f32', [gp, st, B, nblk, H * W, Cout, 32, 1e-6], [1])
+    scratch = np.zeros(hip.gn_scratch_elems(B, H * W, Cout, 32), np.float64)
+    (g1,), _ = both('gn_stats_f32', [g, np.zeros_like(st), scratch, B, H * W, Cout, 32, 1e-6], [1])
+    check('upconv stats from partials vs statistics kernel', gs, g1, exact=False, atol=1e-6, rtol=2e-6)
+
+
 @pytest.mark.parametrize('B,HW,C', [(2, 9, 32), (2, 256, 640), (1, 4096, 320), (2, 2304, 160), (3, 100, 64)])
 def test_groupnorm(B, HW, C):
     _, hip = _setup()

@@ -43,6 +43,9 @@ SIGNATURES = {
     'quant_accum_h_f32': [P, P, P, P, P, F, P, P, I, I, I, I],
     'gumbel_softmax_f32': [P, P, P, L, I, F, F],
     'gemm_qkv_f32':      [P, L, P, L, P, I, I, I, P, F, I, P, P, P, I, I, I, I, I],
+    'conv3x3_gn_nhwc_f32': [P, P, P, P, P, P, I, I, I, I, I, I],
+    'upconv_phase_gn_f32': [P, P, P, P, P, I, I, I, I, I],
+    'gn_stats_part_f32': [P, P, I, I, I, I, I, F],
     'neighbor_table_f32': [P, I, I, I, P, P],
     'smooth_select_f32': [P, P, P, P, I, I, I, F, F, I, I, I, D, P, P, P, P],
 }
@@ -63,6 +66,10 @@ def bind(lib, prefix: str, with_stream: bool):
     gs.argtypes = [I, I, I, I]
     gs.restype = L
     fns['gn_scratch_elems'] = gs
+    cb = getattr(lib, prefix + 'conv_gn_blocks')
+    cb.argtypes = [I, I, I, I]
+    cb.restype = I
+    fns['conv_gn_blocks'] = cb
     ver = getattr(lib, prefix + 'version')
     ver.argtypes = []
     ver.restype = C.c_char_p

@@ -17,6 +17,9 @@ struct GemmP {
     int evec;                                   // epilogue may use 16-byte accesses (N, leading dims and pointers allow it)
     // epi == 3 (fused q/k/v epilogue, varhip_gemm_qkv_f32): N = 3C, head_dim 64
     const float* q_smul; float* q_out; float* q_kc; float* q_vc; float q_plain; int q_l2, q_l, q_pos0, q_Lmax;
+    // convolution: optional per-block per-channel (sum, sum of squares) of the result, [B][blocks per sample][Cout][2] doubles, for
+    // the GroupNorm that follows (saves its statistics pass over the tensor)
+    double* gn_part;
 };
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -291,6 +294,7 @@ __global__ void __launch_bounds__(256) k_dma_gemm(GemmP p) {
             if (full) b4 = *(const f32x4*)(p.bias + n);
             else { for (int e = 0; e < 4; ++e) if (n + e < p.N) b4[e] = p.bias[n + e]; }
         }
+        double gs[4] = {0.0, 0.0, 0.0, 0.0}, gq[4] = {0.0, 0.0, 0.0, 0.0};     // GroupNorm partials of this lane's 4 channels (CONV, gn_part)
 #pragma unroll
         for (int i = 0; i < TMW; ++i) {
             const int m = m0 + (wm * TMW + i) * 16 + r16;
@@ -321,6 +325,10 @@ __global__ void __launch_bounds__(256) k_dma_gemm(GemmP p) {
                     v = *(const f32x4*)(p.resid + (int64_t)m * p.ldr + n) + v;
                 }
                 *(f32x4*)(Ob + mo * p.ldo + n) = v;
+                if (CONV && p.gn_part) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const double d = (double)v[e]; gs[e] += d; gq[e] += d * d; }
+                }
             } else {
                 for (int e = 0; e < 4; ++e) {
                     if (n + e >= p.N) break;
@@ -331,6 +339,36 @@ __global__ void __launch_bounds__(256) k_dma_gemm(GemmP p) {
                     }
                     Ob[mo * p.ldo + n + e] = x;
                 }
+            }
+        }
+        if constexpr (CONV && NST == 2) {
+            if (p.gn_part) {
+                // sum over the wave's 16 pixel lanes (fixed butterfly), then park the 4 channel sums of this (wm, j, kq) in LDS: the
+                // K-loop stages are free, the loop ended on a barrier.  The host guarantees full tiles (M % BM == 0, N % BN == 0).
+#pragma unroll
+                for (int off = 8; off >= 1; off >>= 1)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { gs[e] += __shfl_xor(gs[e], off, 64); gq[e] += __shfl_xor(gq[e], off, 64); }
+                if (r16 == 0) {
+                    double* red = reinterpret_cast<double*>(smem);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int nl = (wn * TNW + j) * 16 + kq * 4 + e;
+                        red[(wm * BN + nl) * 2] = gs[e]; red[(wm * BN + nl) * 2 + 1] = gq[e];
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (CONV && NST == 2) {
+        if (p.gn_part) {
+            __syncthreads();
+            if (tid < BN) {
+                const double* red = reinterpret_cast<const double*>(smem);
+                const double s = red[tid * 2] + red[(BN + tid) * 2], q = red[tid * 2 + 1] + red[(BN + tid) * 2 + 1];
+                const int hw = p.H * p.Wd, b = m0 / hw, per = hw / BM, blk = bz * per + (m0 - b * hw) / BM, nblk = (int)gridDim.z * per;
+                double* o = p.gn_part + (((int64_t)b * nblk + blk) * p.N + n0 + tid) * 2;
+                o[0] = s; o[1] = q;
             }
         }
     }
@@ -431,9 +469,17 @@ extern "C" int varhip_gemm_qkv_f32(const float* A, int64_t lda, const float* W, 
     return big ? launch_dma<4, 4>(p, 1, (hipStream_t)stream) : launch_dma<2, 4>(p, 1, (hipStream_t)stream);
 }
 
-extern "C" int varhip_conv3x3_nhwc_f32(const float* in, const float* w, const float* bias, const float* resid, float* out,
-                                       int B, int H, int W, int Cin, int Cout, int up2, int out_mode, varhip_stream_t stream) {
+// GroupNorm partials from the conv epilogue: blocks of 128 consecutive pixels never straddle samples and tiles are full
+extern "C" int varhip_conv_gn_blocks(int H, int W, int Cout, int phase) {
+    const int hw = phase ? (H / 2) * (W / 2) : H * W;
+    if (H <= 0 || W <= 0 || Cout <= 0 || (Cout & 31) || (hw & 127) || (phase && ((H & 1) || (W & 1)))) return 0;
+    return (phase ? 4 : 1) * (hw / 128);
+}
+
+static int conv3x3_impl(const float* in, const float* w, const float* bias, const float* resid, float* out, double* gn_part,
+                        int B, int H, int W, int Cin, int Cout, int up2, int out_mode, varhip_stream_t stream) {
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (Cin & 31) || !bias) return VARHIP_EINVAL;
+    if (gn_part && (out_mode != 0 || !varhip_conv_gn_blocks(H, W, Cout, 0))) return VARHIP_EINVAL;
     if (up2 && ((H & 1) || (W & 1))) return VARHIP_EINVAL;
     if (out_mode < 0 || out_mode > 2 || (out_mode != 0 && resid)) return VARHIP_EINVAL;
     if ((int64_t)B * H * W >= (1ll << 31)) return VARHIP_EINVAL;
@@ -443,11 +489,22 @@ extern "C" int varhip_conv3x3_nhwc_f32(const float* in, const float* w, const fl
     p.M = B * H * W; p.N = Cout; p.K = 9 * Cin; p.epi = resid ? VARHIP_EPI_RESID : VARHIP_EPI_NONE; p.rows_per_group = 1;
     p.H = H; p.Wd = W; p.Cin = Cin; p.up2 = up2; p.out_mode = out_mode; p.Hi = up2 ? H / 2 : H; p.Wi = up2 ? W / 2 : W;
     p.evec = !((Cout & 3) || ((uintptr_t)out & 15) || ((uintptr_t)bias & 15) || (resid && ((uintptr_t)resid & 15)));
+    if (gn_part && !p.evec) return VARHIP_EINVAL;
+    p.gn_part = gn_part;
     const double npix = (double)B * H * W;
     VhScope scope(VH_FAM_CONV, (hipStream_t)stream, 2.0 * npix * Cout * 9.0 * Cin,
                   4.0 * (npix * Cin / (up2 ? 4.0 : 1.0) + npix * Cout * (resid ? 2.0 : 1.0) + 9.0 * Cin * Cout));
     hipStream_t s = (hipStream_t)stream;
     return launch_conv(p, 1, s);
+}
+extern "C" int varhip_conv3x3_nhwc_f32(const float* in, const float* w, const float* bias, const float* resid, float* out,
+                                       int B, int H, int W, int Cin, int Cout, int up2, int out_mode, varhip_stream_t stream) {
+    return conv3x3_impl(in, w, bias, resid, out, nullptr, B, H, W, Cin, Cout, up2, out_mode, stream);
+}
+extern "C" int varhip_conv3x3_gn_nhwc_f32(const float* in, const float* w, const float* bias, const float* resid, float* out, double* gn_part,
+                                          int B, int H, int W, int Cin, int Cout, int up2, varhip_stream_t stream) {
+    if (!gn_part) return VARHIP_EINVAL;
+    return conv3x3_impl(in, w, bias, resid, out, gn_part, B, H, W, Cin, Cout, up2, 0, stream);
 }
 
 // ---- Downsample2x of the encoder (basic_vae.py:31-37): F.pad(x, (0,1,0,1)) then Conv2d(k=3, stride=2, padding=0) -------------
@@ -494,10 +551,11 @@ extern "C" int varhip_upconv_pack_f32(const float* w, float* w_phase, int Cin, i
     return vh_launch_status();
 }
 
-extern "C" int varhip_upconv_phase_f32(const float* in, const float* w_phase, const float* bias, float* out,
-                                       int B, int H, int W, int Cin, int Cout, varhip_stream_t stream) {
+static int upconv_phase_impl(const float* in, const float* w_phase, const float* bias, float* out, double* gn_part,
+                             int B, int H, int W, int Cin, int Cout, varhip_stream_t stream) {
     // in: [B][H/2][W/2][Cin]; out: [B][H][W][Cout]; w_phase from varhip_upconv_pack_f32
     if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || Cin <= 0 || Cout <= 0 || (Cin & 31) || !bias) return VARHIP_EINVAL;
+    if (gn_part && !varhip_conv_gn_blocks(H, W, Cout, 1)) return VARHIP_EINVAL;
     if ((int64_t)B * H * W >= (1ll << 31)) return VARHIP_EINVAL;
     GemmP p{};
     p.A = in; p.W = w_phase; p.bias = bias; p.out = out; p.resid = nullptr; p.gamma = nullptr;
@@ -505,8 +563,19 @@ extern "C" int varhip_upconv_phase_f32(const float* in, const float* w_phase, co
     p.M = B * (H / 2) * (W / 2); p.N = Cout; p.K = 4 * Cin; p.epi = VARHIP_EPI_NONE; p.rows_per_group = 1;
     p.H = H / 2; p.Wd = W / 2; p.Cin = Cin; p.up2 = 2; p.out_mode = 0; p.Hi = H / 2; p.Wi = W / 2;
     p.evec = !((Cout & 3) || ((uintptr_t)out & 15) || ((uintptr_t)bias & 15));
+    if (gn_part && !p.evec) return VARHIP_EINVAL;
+    p.gn_part = gn_part;
     const double npix = (double)B * H * W;
     VhScope scope(VH_FAM_CONV, (hipStream_t)stream, 2.0 * npix * Cout * 4.0 * Cin, 4.0 * (npix * Cin / 4.0 + npix * Cout + 16.0 * Cin * Cout));
     hipStream_t s = (hipStream_t)stream;
     return launch_conv(p, 4, s);
+}
+extern "C" int varhip_upconv_phase_f32(const float* in, const float* w_phase, const float* bias, float* out,
+                                       int B, int H, int W, int Cin, int Cout, varhip_stream_t stream) {
+    return upconv_phase_impl(in, w_phase, bias, out, nullptr, B, H, W, Cin, Cout, stream);
+}
+extern "C" int varhip_upconv_phase_gn_f32(const float* in, const float* w_phase, const float* bias, float* out, double* gn_part,
+                                          int B, int H, int W, int Cin, int Cout, varhip_stream_t stream) {
+    if (!gn_part) return VARHIP_EINVAL;
+    return upconv_phase_impl(in, w_phase, bias, out, gn_part, B, H, W, Cin, Cout, stream);
 }

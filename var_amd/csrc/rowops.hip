@@ -235,6 +235,34 @@ extern "C" int varhip_gn_stats_f32(const float* x, float* stats, double* scratch
     return vh_launch_status();
 }
 
+// statistics from the per-block per-channel partials a convolution left behind (varhip_conv3x3_gn_nhwc_f32): blocks in order,
+// channels of the group in order, fp64
+__global__ void __launch_bounds__(64) k_gn_final_part(const double* __restrict__ part, float* __restrict__ stats, int G, int nblk, int C, double count, float eps) {
+    // one wave per (sample, group): lane j sums blocks j, j+64, ... (channels of the group in order), then a fixed butterfly
+    const int i = blockIdx.x, lane = threadIdx.x;
+    const int b = i / G, g = i - b * G, cpg = C / G;
+    double s = 0.0, s2 = 0.0;
+    for (int k = lane; k < nblk; k += 64) {
+        const double* o = part + (((int64_t)b * nblk + k) * C + g * cpg) * 2;
+        for (int c = 0; c < cpg; ++c) { s += o[2 * c]; s2 += o[2 * c + 1]; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { s += __shfl_xor(s, off, 64); s2 += __shfl_xor(s2, off, 64); }
+    if (lane == 0) {
+        const double mean = s / count;
+        double var = s2 / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stats[2 * i] = (float)mean;
+        stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+extern "C" int varhip_gn_stats_part_f32(const double* part, float* stats, int B, int nblk, int HW, int C, int G, float eps, varhip_stream_t stream) {
+    if (B <= 0 || nblk <= 0 || HW <= 0 || C <= 0 || G <= 0 || (C % G) || !part) return VARHIP_EINVAL;
+    VhScope sc(VH_FAM_GN, (hipStream_t)stream, 0, 16.0 * B * (double)nblk * C);
+    hipLaunchKernelGGL(k_gn_final_part, dim3(B * G), dim3(64), 0, (hipStream_t)stream, part, stats, G, nblk, C, (double)HW * (C / G), eps);
+    return vh_launch_status();
+}
+
 // SiLU of the decoder's GroupNorm: hardware exp2 / rcp (about 1 ulp each) instead of include/var_math.h's reproducible forms.
 // The decoder is off the token path (pixels within 1e-3 of the reference, measured ~1e-6); this halves the kernel's VALU work.
 __device__ __forceinline__ float gn_fast_silu(float y) {

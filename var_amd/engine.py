@@ -110,18 +110,35 @@ class DecoderEngine(_VaeOps):
         self._sig = sig
 
     # -- building blocks ---------------------------------------------------------------------------------------------
-    def conv3(self, x, key, B, Hh, Ww, up2=0, resid=None, out_mode=0):
+    def _part_buffer(self, B, nblk, Cout, dev):
+        """scratch for the GroupNorm partials a conv leaves behind; remembered together with the tensor they describe"""
+        return torch.empty((B, nblk, Cout, 2), dtype=torch.float64, device=dev)
+
+    def conv3(self, x, key, B, Hh, Ww, up2=0, resid=None, out_mode=0, stats=False):
+        """stats=True: the result feeds a GroupNorm next — the conv epilogue also emits per-block channel sums (when the shape
+        allows), which gn() then uses instead of a statistics pass over the tensor."""
         wt = self.w[key + '.weight']
         Cout, Cin = wt.shape[0], wt.shape[3]
         out = torch.empty((B, Cout, Hh, Ww) if out_mode else (B, Hh, Ww, Cout), dtype=torch.float32, device=x.device)
-        hip.call('conv3x3_nhwc_f32', x, wt, self.w[key + '.bias'], resid, out, B, Hh, Ww, Cin, Cout, up2, out_mode)
+        nblk = hip.conv_gn_blocks(Hh, Ww, Cout) if (stats and out_mode == 0) else 0
+        if nblk:
+            part = self._part_buffer(B, nblk, Cout, x.device)
+            hip.call('conv3x3_gn_nhwc_f32', x, wt, self.w[key + '.bias'], resid, out, part, B, Hh, Ww, Cin, Cout, up2)
+            self._gn_part = (out, part, nblk)              # holds `out` so its address cannot be recycled before the next gn()
+        else:
+            hip.call('conv3x3_nhwc_f32', x, wt, self.w[key + '.bias'], resid, out, B, Hh, Ww, Cin, Cout, up2, out_mode)
         return out
 
     def gn(self, x, key, B, HW, silu):
         Cc = x.shape[-1]
         stats = torch.empty((B, 32, 2), dtype=torch.float32, device=x.device)
-        scratch = torch.empty(hip.gn_scratch_elems(B, HW, Cc, 32), dtype=torch.float64, device=x.device)
-        hip.call('gn_stats_f32', x, stats, scratch, B, HW, Cc, 32, 1e-6)
+        pend = getattr(self, '_gn_part', None)
+        self._gn_part = None
+        if pend is not None and pend[0].data_ptr() == x.data_ptr() and pend[0].numel() == x.numel() and tuple(pend[1].shape) == (B, pend[2], Cc, 2):
+            hip.call('gn_stats_part_f32', pend[1], stats, B, pend[2], HW, Cc, 32, 1e-6)
+        else:
+            scratch = torch.empty(hip.gn_scratch_elems(B, HW, Cc, 32), dtype=torch.float64, device=x.device)
+            hip.call('gn_stats_f32', x, stats, scratch, B, HW, Cc, 32, 1e-6)
         out = torch.empty_like(x)
         hip.call('gn_apply_f32', x, stats, self.w[key + '.weight'], self.w[key + '.bias'], out, B, HW, Cc, 32, int(silu))
         return out
@@ -137,9 +154,10 @@ class DecoderEngine(_VaeOps):
 
     def resblock(self, x, pre, B, Hh, Ww):
         HW = Hh * Ww
-        h = self.conv3(self.gn(x, pre + '.norm1', B, HW, True), pre + '.conv1', B, Hh, Ww)
+        h = self.conv3(self.gn(x, pre + '.norm1', B, HW, True), pre + '.conv1', B, Hh, Ww, stats=True)        # -> norm2
+        hn = self.gn(h, pre + '.norm2', B, HW, True)
         sc = self.lin(x.view(B * HW, -1), pre + '.nin_shortcut').view(B, Hh, Ww, -1) if (pre + '.nin_shortcut.weight') in self.w else x
-        return self.conv3(self.gn(h, pre + '.norm2', B, HW, True), pre + '.conv2', B, Hh, Ww, resid=sc)
+        return self.conv3(hn, pre + '.conv2', B, Hh, Ww, resid=sc, stats=True)                                  # -> the next block's norm
 
     def attnblock(self, x, pre, B, Hh, Ww):
         HW, Cc = Hh * Ww, x.shape[-1]
@@ -185,7 +203,7 @@ class DecoderEngine(_VaeOps):
         B, P = f_hat.shape[0], f_hat.shape[1]
         Hh = Ww = P
         h = self.conv3(f_hat, 'post_quant_conv', B, Hh, Ww)
-        h = self.conv3(h, 'decoder.conv_in', B, Hh, Ww)
+        h = self.conv3(h, 'decoder.conv_in', B, Hh, Ww, stats=True)
         h = self.resblock(h, 'decoder.mid.block_1', B, Hh, Ww)
         h = self.attnblock(h, 'decoder.mid.attn_1', B, Hh, Ww)
         h = self.resblock(h, 'decoder.mid.block_2', B, Hh, Ww)
@@ -199,7 +217,13 @@ class DecoderEngine(_VaeOps):
                 key = f'decoder.up.{lev}.upsample.conv'
                 wp = self.w[key + '.phase']
                 up = torch.empty((B, Hh, Ww, wp.shape[1]), dtype=torch.float32, device=h.device)
-                hip.call('upconv_phase_f32', h, wp, self.w[key + '.bias'], up, B, Hh, Ww, wp.shape[4], wp.shape[1])
+                nblk = hip.conv_gn_blocks(Hh, Ww, wp.shape[1], phase=True)
+                if nblk:                                             # its result is normalised by the next level's first ResnetBlock
+                    part = self._part_buffer(B, nblk, wp.shape[1], h.device)
+                    hip.call('upconv_phase_gn_f32', h, wp, self.w[key + '.bias'], up, part, B, Hh, Ww, wp.shape[4], wp.shape[1])
+                    self._gn_part = (up, part, nblk)
+                else:
+                    hip.call('upconv_phase_f32', h, wp, self.w[key + '.bias'], up, B, Hh, Ww, wp.shape[4], wp.shape[1])
                 h = up
         h = self.gn(h, 'decoder.norm_out', B, Hh * Ww, True)
         return self.conv3(h, 'decoder.conv_out', B, Hh, Ww, out_mode=1 if denorm else 2)

@@ -66,6 +66,11 @@ def gn_scratch_elems(B, HW, C, G) -> int:
     return int(lib().fn['gn_scratch_elems'](B, HW, C, G))
 
 
+def conv_gn_blocks(H, W, Cout, phase=False) -> int:
+    """blocks per sample of the GroupNorm partials a conv can leave behind (0: unsupported shape)"""
+    return int(lib().fn['conv_gn_blocks'](H, W, Cout, 1 if phase else 0))
+
+
 # ---- timing table --------------------------------------------------------------------------------------------------
 def timing_enable(on: bool):
     lib().so.varhip_timing_enable(1 if on else 0)
