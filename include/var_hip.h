@@ -89,6 +89,19 @@ int varhip_gemm_qkv_f32(const float* A, int64_t lda, const float* W, int64_t ldw
 int varhip_attn_cached_f32(const float* q, const float* kcache, const float* vcache, float* out,
                            int B2, int l, int H, int curL, int Lmax, varhip_stream_t stream);
 
+/* ---- one AdaLNSelfAttn block (basic_var.py:152-159) in one call ---------------------------------------------
+ * x <- x + gamma1 * proj(attn(LN(x)(1+scale1)+shift1));  x <- x + gamma2 * fc2(gelu(fc1(LN(x)(1+scale2)+shift2)))
+ * issued as the seven launches ln_modulate, gemm_qkv, attn_cached, gemm_nt(RESID), ln_modulate, gemm_nt(GELU),
+ * gemm_nt(RESID) with exactly their arithmetic.  ada: this block's [B2][6C] AdaLN rows (gamma1|gamma2|scale1|scale2|shift1|
+ * shift2, row stride ld_ada); x2, xn, q, att, hid are workspaces ([M][C], hid [M][hidden]); the result is left in x.
+ * A host that pays ~10 us per FFI call would otherwise starve the GPU at the small scales (launches of 5-20 us). */
+int varhip_adaln_block_f32(float* x, float* x2, float* xn, float* q, float* att, float* hid,
+                           const float* ada, int64_t ld_ada,
+                           const float* qkv_w, const float* qkv_b, const float* scale_mul, float plain_scale, int l2norm,
+                           const float* proj_w, const float* proj_b, const float* fc1_w, const float* fc1_b,
+                           const float* fc2_w, const float* fc2_b, float* kcache, float* vcache,
+                           int B2, int l, int C, int H, int hidden, int pos0, int Lmax, float eps, varhip_stream_t stream);
+
 /* ---- classifier-free guidance + top-k/top-p + multinomial(1) -------------------------------------------
  * logits: [2B][l][V] (rows 0..B-1 conditional, B..2B-1 unconditional).  For row r=(b,t):
  *   x = (float)(1+t_cfg) * cond - (float)t_cfg * uncond                             (var.py:172-173)
@@ -235,6 +248,9 @@ int varhip_nearest_code_f32(const float* z, const float* codebook, int64_t* idx_
  * and element-wise-load variants).  Returns the number of families. */
 #define VARHIP_NFAM 9
 int varhip_timing_enable(int on);
+/* restrict the timing to the families whose bit is set (default: all).  Every timed launch costs two event records on the stream —
+ * about 2 % of a sampling call when all ~3000 launches are timed; bench.py times only what its roofline object reports. */
+int varhip_timing_select(int family_mask);
 int varhip_timing_reset(void);
 int varhip_timing_read(double* ms, double* flops, double* bytes, int64_t* launches);
 const char* varhip_timing_name(int family);

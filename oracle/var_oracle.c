@@ -214,6 +214,28 @@ int varref_gemm_qkv_f32(const float* A, int64_t lda, const float* W, int64_t ldw
     return rc;
 }
 
+/* forward declarations for the composite below */
+int varref_attn_cached_f32(const float* q, const float* kcache, const float* vcache, float* out, int B2, int l, int H, int curL, int Lmax);
+
+/* AdaLNSelfAttn.forward (basic_var.py:152-159) as the seven steps above, in order: twin of varhip_adaln_block_f32 */
+int varref_adaln_block_f32(float* x, float* x2, float* xn, float* q, float* att, float* hid, const float* ada, int64_t ld_ada,
+                           const float* qkv_w, const float* qkv_b, const float* scale_mul, float plain_scale, int l2norm,
+                           const float* proj_w, const float* proj_b, const float* fc1_w, const float* fc1_b,
+                           const float* fc2_w, const float* fc2_b, float* kcache, float* vcache,
+                           int B2, int l, int C, int H, int hidden, int pos0, int Lmax, float eps) {
+    if (B2 <= 0 || l <= 0 || C != H * 64 || hidden <= 0 || !ada) return VARHIP_EINVAL;
+    const int M = B2 * l;
+    const float *g1 = ada, *g2 = ada + C, *s1 = ada + 2 * C, *s2 = ada + 3 * C, *h1 = ada + 4 * C, *h2 = ada + 5 * C;
+    int rc;
+    if ((rc = varref_ln_modulate_f32(x, s1, ld_ada, h1, ld_ada, xn, M, C, l, eps))) return rc;
+    if ((rc = varref_gemm_qkv_f32(xn, C, qkv_w, C, qkv_b, M, C, C, scale_mul, plain_scale, l2norm, q, kcache, vcache, B2, l, H, pos0, Lmax))) return rc;
+    if ((rc = varref_attn_cached_f32(q, kcache, vcache, att, B2, l, H, pos0 + l, Lmax))) return rc;
+    if ((rc = varref_gemm_nt_f32(att, C, proj_w, C, proj_b, x2, C, M, C, C, EPI_RESID, x, C, g1, ld_ada, l, 0, 1, 0, 0, 0))) return rc;
+    if ((rc = varref_ln_modulate_f32(x2, s2, ld_ada, h2, ld_ada, xn, M, C, l, eps))) return rc;
+    if ((rc = varref_gemm_nt_f32(xn, C, fc1_w, C, fc1_b, hid, hidden, M, hidden, C, EPI_GELU, NULL, 0, NULL, 0, 1, 0, 1, 0, 0, 0))) return rc;
+    return varref_gemm_nt_f32(hid, hidden, fc2_w, hidden, fc2_b, x, C, M, C, hidden, EPI_RESID, x2, C, g2, ld_ada, l, 0, 1, 0, 0, 0);
+}
+
 /* slow_attn / SDPA without mask over the cached keys (basic_var.py:111-117).  Row sum of the softmax numerators:
  * (sum over even key positions) + (sum over odd key positions), each ascending — see DESIGN.md §Numerics. */
 int varref_attn_cached_f32(const float* q, const float* kcache, const float* vcache, float* out,

@@ -137,6 +137,28 @@ def test_gemm_qkv_fused_epilogue_exact(B2, l, H, K, pos0, Lmax, l2):
         check(f'gemm_qkv {nm}', g, w)
 
 
+@pytest.mark.parametrize('B2,l,H,hidden,pos0,Lmax,l2', [(4, 9, 2, 512, 5, 14, 1), (2, 16, 3, 768, 0, 16, 0), (6, 1, 16, 4096, 0, 5, 1)])
+def test_adaln_block_composite_exact(B2, l, H, hidden, pos0, Lmax, l2):
+    """one AdaLNSelfAttn block behind a single call == its CPU twin (which is the same seven steps on the oracle's functions)"""
+    rng = np.random.default_rng(B2 * l + H)
+    C, M = 64 * H, B2 * l
+    x = rnd(rng, M, C); ada = rnd(rng, B2, 6 * C, scale=0.3)
+    ws = [np.zeros((M, C), np.float32) for _ in range(4)]; hid = np.zeros((M, hidden), np.float32)
+    qkv_w = rnd(rng, 3 * C, C, scale=0.05); qkv_b = rnd(rng, 3 * C, scale=0.1)
+    sm = (np.log(4.0) + rnd(rng, H, scale=0.5)).astype(np.float32)
+    proj_w = rnd(rng, C, C, scale=0.05); proj_b = rnd(rng, C, scale=0.1)
+    fc1_w = rnd(rng, hidden, C, scale=0.05); fc1_b = rnd(rng, hidden, scale=0.1)
+    fc2_w = rnd(rng, C, hidden, scale=0.03); fc2_b = rnd(rng, C, scale=0.1)
+    kc = rnd(rng, B2, H, Lmax, 64, scale=0.2); vc = rnd(rng, B2, H, Lmax, 64)
+    if l2:                                           # cached keys of earlier scales are unit vectors in the real loop
+        kc /= np.maximum(np.linalg.norm(kc, axis=-1, keepdims=True), 1e-6)
+    args = [x, ws[0], ws[1], ws[2], ws[3], hid, ada, 6 * C, qkv_w, qkv_b, sm if l2 else None, 0.03125, l2, proj_w, proj_b, fc1_w, fc1_b, fc2_w, fc2_b,
+            kc, vc, B2, l, C, H, hidden, pos0, Lmax, 1e-6]
+    outs_h, outs_r = both('adaln_block_f32', args, [0, 19, 20])
+    for nm, g, w in zip(('x', 'kcache', 'vcache'), outs_h, outs_r):
+        check(f'adaln_block {nm}', g, w)
+
+
 @pytest.mark.parametrize('V,D,n', [(4096, 32, 6), (512, 8, 512), (300, 5, 17), (8192, 16, 3)])
 def test_neighbor_table_exact(V, D, n):
     """smooth_sampling's neighbour table: ascending distance, ties by index (duplicated codes force ties), self first"""

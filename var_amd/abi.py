@@ -46,6 +46,7 @@ SIGNATURES = {
     'conv3x3_gn_nhwc_f32': [P, P, P, P, P, P, I, I, I, I, I, I],
     'upconv_phase_gn_f32': [P, P, P, P, P, I, I, I, I, I],
     'gn_stats_part_f32': [P, P, I, I, I, I, I, F],
+    'adaln_block_f32':   [P, P, P, P, P, P, P, L, P, P, P, F, I, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, F],
     'neighbor_table_f32': [P, I, I, I, P, P],
     'smooth_select_f32': [P, P, P, P, I, I, I, F, F, I, I, I, D, P, P, P, P],
 }

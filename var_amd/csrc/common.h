@@ -20,13 +20,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define VH_FAM_GEMM_SMALL 8
 
 // ---- timing table (timing.cpp) ------------------------------------------------------------------------------------
-int vh_timing_on();
+int vh_timing_on(int fam);
 void vh_timing_begin(int fam, hipStream_t s, double flops, double bytes);
 void vh_timing_end(int fam, hipStream_t s);
 
 struct VhScope {           // brackets one launch with events when timing is enabled
     int fam; hipStream_t s; bool on;
-    VhScope(int f, hipStream_t st, double flops, double bytes) : fam(f), s(st), on(vh_timing_on() != 0) { if (on) vh_timing_begin(fam, s, flops, bytes); }
+    VhScope(int f, hipStream_t st, double flops, double bytes) : fam(f), s(st), on(vh_timing_on(f) != 0) { if (on) vh_timing_begin(fam, s, flops, bytes); }
     ~VhScope() { if (on) vh_timing_end(fam, s); }
 };
 

@@ -7,6 +7,7 @@ namespace {
 struct Rec { hipEvent_t a, b; int fam; };
 std::mutex g_mu;
 int g_on = 0;
+int g_mask = ~0;             // families that are timed when timing is on
 std::vector<Rec> g_pool;          // created lazily, reused
 size_t g_used = 0;
 double g_ms[VARHIP_NFAM], g_flops[VARHIP_NFAM], g_bytes[VARHIP_NFAM];
@@ -23,7 +24,7 @@ void drain_locked() {
 }
 }  // namespace
 
-int vh_timing_on() { return g_on; }
+int vh_timing_on(int fam) { return g_on && ((g_mask >> fam) & 1); }
 
 void vh_timing_begin(int fam, hipStream_t s, double flops, double bytes) {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -49,6 +50,7 @@ extern "C" {
 const char* varhip_version(void) { return "var_hip 0.1.0 gfx950"; }
 
 int varhip_timing_enable(int on) { std::lock_guard<std::mutex> lk(g_mu); g_on = on ? 1 : 0; return 0; }
+int varhip_timing_select(int family_mask) { std::lock_guard<std::mutex> lk(g_mu); g_mask = family_mask; return 0; }
 
 int varhip_timing_reset(void) {
     std::lock_guard<std::mutex> lk(g_mu);

@@ -445,6 +445,15 @@ class SamplingEngine:
             tabs[n] = (idx, dist)
         return tabs[n]
 
+    def block(self, blk, ws, bi, x, x2, rows, l, cur):
+        """one AdaLNSelfAttn block (basic_var.py:152-159): seven launches behind one library call; the result is left in x"""
+        var = self.var
+        C = var.C
+        hip.call('adaln_block_f32', x, x2, ws['xn'], ws['q'], ws['att'], ws['hid'], ws['ada'][bi], 6 * C,
+                 blk['qkv_w'], blk['qkv_b'], blk['smul'], blk['plain_scale'], int(blk['l2']), blk['proj_w'], blk['proj_b'],
+                 blk['fc1_w'], blk['fc1_b'], blk['fc2_w'], blk['fc2_b'], ws['kc'][bi], ws['vc'][bi],
+                 rows, l, C, var.num_heads, blk['fc1_w'].shape[0], cur, var.L, var.norm_eps)
+
     def qkv(self, xn, blk, ws, bi, rows, l, cur):
         """mat_qkv + q/k normalisation + KV-cache append in one launch (basic_var.py:93-109)."""
         C, H = self.var.C, self.var.num_heads
@@ -537,15 +546,7 @@ class SamplingEngine:
             l = pn * pn
             M = B2 * l
             for bi, blk in enumerate(w['blocks']):                        # AdaLNSelfAttn.forward, basic_var.py:152-159
-                ada = ws['ada'][bi]
-                g1, g2, s1, s2, h1, h2 = (ada[:, i * C:] for i in range(6))       # interior pointers, row stride 6C
-                hip.call('ln_modulate_f32', x, s1, 6 * C, h1, 6 * C, ws['xn'], M, C, l, var.norm_eps)
-                self.qkv(ws['xn'], blk, ws, bi, B2, l, cur)
-                hip.call('attn_cached_f32', ws['q'], ws['kc'][bi], ws['vc'][bi], ws['att'], B2, l, H, cur + l, var.L)
-                self.gemm(ws['att'], blk['proj_w'], blk['proj_b'], x2, M, EPI_RESID, resid=x, gamma=g1, ldg=6 * C, rpg=l)
-                hip.call('ln_modulate_f32', x2, s2, 6 * C, h2, 6 * C, ws['xn'], M, C, l, var.norm_eps)
-                self.gemm(ws['xn'], blk['fc1_w'], blk['fc1_b'], ws['hid'], M, EPI_GELU)
-                self.gemm(ws['hid'], blk['fc2_w'], blk['fc2_b'], x, M, EPI_RESID, resid=x2, gamma=g2, ldg=6 * C, rpg=l)
+                self.block(blk, ws, bi, x, x2, B2, l, cur)
             cur += l
             if skip is not None and skip[si]:
                 # inpainting, every token of this scale is kept: no head, no sampling, no RNG draw (var.py:312-313, fork)
@@ -659,15 +660,7 @@ class SamplingEngine:
                 seg = xin[:, cur - var.first_l:cur - var.first_l + l].contiguous()
                 hip.call('word_embed_f32', seg, w['word_w'], w['word_b'], ws['lvl_pos'][cur:], x, R, l, C, Cv)
             for bi, blk in enumerate(w['blocks']):
-                ada = ws['ada'][bi]
-                g1, g2, s1, s2, h1, h2 = (ada[:, i * C:] for i in range(6))
-                hip.call('ln_modulate_f32', x, s1, 6 * C, h1, 6 * C, ws['xn'], M, C, l, var.norm_eps)
-                self.qkv(ws['xn'], blk, ws, bi, R, l, cur)
-                hip.call('attn_cached_f32', ws['q'], ws['kc'][bi], ws['vc'][bi], ws['att'], R, l, H, cur + l, L)
-                self.gemm(ws['att'], blk['proj_w'], blk['proj_b'], x2, M, EPI_RESID, resid=x, gamma=g1, ldg=6 * C, rpg=l)
-                hip.call('ln_modulate_f32', x2, s2, 6 * C, h2, 6 * C, ws['xn'], M, C, l, var.norm_eps)
-                self.gemm(ws['xn'], blk['fc1_w'], blk['fc1_b'], ws['hid'], M, EPI_GELU)
-                self.gemm(ws['hid'], blk['fc2_w'], blk['fc2_b'], x, M, EPI_RESID, resid=x2, gamma=g2, ldg=6 * C, rpg=l)
+                self.block(blk, ws, bi, x, x2, R, l, cur)
             hn = ws['hn']
             hip.call('ln_modulate_f32', x, hn, 2 * C, hn[:, C:], 2 * C, ws['xn'], M, C, l, var.norm_eps)
             self.gemm(ws['xn'], w['head_w'], w['head_b'], ws['lg'], M)

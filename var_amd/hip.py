@@ -72,8 +72,15 @@ def conv_gn_blocks(H, W, Cout, phase=False) -> int:
 
 
 # ---- timing table --------------------------------------------------------------------------------------------------
-def timing_enable(on: bool):
-    lib().so.varhip_timing_enable(1 if on else 0)
+def timing_enable(on: bool, families=None):
+    """families: names of the kernel families to time (None = all); each timed launch records two events on the stream"""
+    so = lib().so
+    mask = -1
+    if families is not None:
+        names = [so.varhip_timing_name(i).decode() for i in range(9)]
+        mask = sum(1 << names.index(f) for f in families)
+    so.varhip_timing_select(mask)
+    so.varhip_timing_enable(1 if on else 0)
 
 
 def timing_reset():
