@@ -439,7 +439,7 @@ extern "C" int varhip_gemm_nt_f32(const float* A, int64_t lda, const float* W, i
 // tile choice of the implicit-GEMM convolutions: the N tile divides Cout (160/320/640 -> 160 wide); Cin % 32 == 0 so that a
 // K tile of 32 lies inside one tap
 static int launch_conv(GemmP& p, int batch, hipStream_t s) {
-    if (p.N % 160 == 0) return launch_dma<4, 5, true>(p, batch, s);
+    if (p.N % 160 == 0) return launch_dma<4, 5, true>(p, batch, s);     // (64x160 tiles were measured: 6 % slower)
     if (p.N % 128 == 0) return launch_dma<4, 4, true>(p, batch, s);
     if (p.N % 64 == 0) return launch_dma<4, 2, true>(p, batch, s);
     return launch_dma<4, 1, true>(p, batch, s);         // (a 4-stage pipeline was measured here: slower, occupancy matters more)
