@@ -14,7 +14,7 @@
 #include "common.h"
 
 #define KLD 68          // K tile row stride (floats): 64 + 4 -> conflict-free ds_read_b128 / ds_write_b128
-#define VLD 64
+#define VLD 36          // V tile is kept TRANSPOSED in LDS: [64 channels][32 keys, permuted] (+4 pad), see store_kv
 #define OLD 65
 #ifndef ATTN_WG_PER_CU
 #define ATTN_WG_PER_CU 4      // workgroups per CU the register allocation is capped for
@@ -30,11 +30,11 @@ __device__ __forceinline__ void swap_pair(f32x16& p) {      // registers (E, E+1
 __global__ void __launch_bounds__(256, ATTN_WG_PER_CU) k_attn_cached(const float* __restrict__ q, const float* __restrict__ kcache, const float* __restrict__ vcache,
                                                      float* __restrict__ out, int l, int H, int curL, int Lmax) {
     // one LDS array: K stages | V stages; the Q staging at the start and the O transpose at the end alias it
-    __shared__ __attribute__((aligned(16))) float smem[2 * 32 * KLD + 2 * 32 * VLD];
+    __shared__ __attribute__((aligned(16))) float smem[2 * 32 * KLD + 2 * 64 * VLD];
     float (*sK)[32 * KLD] = reinterpret_cast<float (*)[32 * KLD]>(smem);
-    float (*sV)[32 * VLD] = reinterpret_cast<float (*)[32 * VLD]>(smem + 2 * 32 * KLD);
+    float (*sV)[64 * VLD] = reinterpret_cast<float (*)[64 * VLD]>(smem + 2 * 32 * KLD);
     float (*sO)[32 * OLD] = reinterpret_cast<float (*)[32 * OLD]>(smem);
-    static_assert(4 * 32 * OLD <= 2 * 32 * KLD + 2 * 32 * VLD, "O staging must fit in the K/V stages");
+    static_assert(4 * 32 * OLD <= 2 * 32 * KLD + 2 * 64 * VLD, "O staging must fit in the K/V stages");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h2 = lane >> 5;
@@ -89,8 +89,14 @@ __global__ void __launch_bounds__(256, ATTN_WG_PER_CU) k_attn_cached(const float
         float* dk = &sK[buf][sr * KLD + sc * 8];
         const f32x4 ev = {gk0[0], gk0[2], gk1[0], gk1[2]}, od = {gk0[1], gk0[3], gk1[1], gk1[3]};    // even k first, then odd k (see gemm notes)
         *(f32x4*)dk = ev; *(f32x4*)(dk + 4) = od;
-        float* dv = &sV[buf][sr * VLD + sc * 8];
-        *(f32x4*)dv = gv0; *(f32x4*)(dv + 4) = gv1;
+        // V^T[c][pos(key)]: inside every 8-key chunk the even keys come first, then the odd keys, so that lane (c, h2) of the PV
+        // MFMAs (A operand = V^T, k = key parity h2) gets the keys of 4 consecutive steps with ONE ds_read_b128 — the same trick
+        // as the K tile; with a [key][c] tile every step paid its own ds_read_b32 round trip.  (The 8 scalar writes below conflict
+        // 8-way on banks; that is ~64 cycles per tile against 4096 cycles of MFMA.)
+        const int pk = (sr & ~7) + ((sr & 1) << 2) + ((sr & 7) >> 1);
+        float* dv = &sV[buf][(sc * 8) * VLD + pk];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { dv[e * VLD] = gv0[e]; dv[(e + 4) * VLD] = gv1[e]; }
     };
     auto scores = [&](int buf, int kt, f32x16& acc) {              // S^T tile: rows = keys, col (lane) = query
 #pragma unroll
@@ -140,18 +146,17 @@ __global__ void __launch_bounds__(256, ATTN_WG_PER_CU) k_attn_cached(const float
         swap_pair<0>(p); swap_pair<2>(p); swap_pair<4>(p); swap_pair<6>(p);
         swap_pair<8>(p); swap_pair<10>(p); swap_pair<12>(p); swap_pair<14>(p);
         // natural key order of the registers: groups of 4 regs (4g..4g+3) hold steps 4g..4g+3 in the order {0,2,1,3}
-        const float* vb = &sV[buf][h2 * VLD + r];
+        const float* vb = &sV[buf][r * VLD + h2 * 4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+            const f32x4 v0 = *(const f32x4*)(vb + g * 8), v1 = *(const f32x4*)(vb + 32 * VLD + g * 8);   // channels r and r+32, steps 4g..4g+3
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int e = 4 * g + ((u & 1) << 1) + (u >> 1);     // u=0,1,2,3 -> reg 4g+{0,2,1,3}
-                const int s = 4 * g + u;                             // MFMA step: keys 2s, 2s+1
+                const int e = 4 * g + ((u & 1) << 1) + (u >> 1);     // u=0,1,2,3 -> reg 4g+{0,2,1,3}; MFMA step s = 4g+u: keys 2s, 2s+1
                 const float pv = p[e];
                 lsum = lsum + pv;
-                const float v0 = vb[(2 * s) * VLD], v1 = vb[(2 * s) * VLD + 32];
-                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, pv, o0, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, pv, o1, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[u], pv, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[u], pv, o1, 0, 0, 0);
             }
         }
         if (kt + 1 < ntile) store_kv(buf ^ 1);                     // stage buf^1 was last read before the previous barrier
