@@ -10,7 +10,7 @@ Extra objects in the JSON line:
   roofline     the dominant kernel family (by device time) of the timed region, measured with HIP events on the launch
                stream by the library's timing table (include/var_hip.h): algorithmic FLOPs / time vs the fp32 MFMA peak.
   cpu_baseline the CPU oracle (oracle/, a scalar C port of the reference algorithm; kind "port") timed on this box's host
-               cores on a bounded sample: two images through all 10 scales + decode (rank 0, N=1 only).
+               cores on a bounded sample: four images through all 10 scales + decode (rank 0, N=1 only).
 """
 import argparse
 import contextlib
@@ -132,7 +132,7 @@ def main():
 
 
 def cpu_baseline(depth, pns):
-    """the CPU oracle on a bounded sample — TWO images (about 12 s), all scales + decode — OpenMP over this box's host cores"""
+    """the CPU oracle on a bounded sample — FOUR images (about 13 s), all scales + decode — OpenMP over this box's host cores"""
     import numpy as np
     import torch
     from oracle.var_oracle import OracleVAR
@@ -150,14 +150,14 @@ def cpu_baseline(depth, pns):
     so = ctypes.CDLL(os.path.join(ROOT, 'oracle', 'libvar_oracle.so'))
     threads = int(so.varref_set_threads(int(os.environ.get('OMP_NUM_THREADS', min(avail, 16)))))   # a 1-GPU box's CPU share is 16 cores
     g = torch.Generator().manual_seed(0)
-    nimg = 2
+    nimg = 4
     noise = [torch.empty(nimg * pn * pn, 4096).exponential_(1, generator=g).numpy() for pn in pns]
     t0 = time.perf_counter()
-    r = orc.run([7, 14][:nimg], noise, 1.5, 900, 0.96)
+    r = orc.run([7, 14, 21, 28][:nimg], noise, 1.5, 900, 0.96)
     dt = time.perf_counter() - t0
     assert np.isfinite(r['img']).all()
     return {'value': round(nimg / dt, 4), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
-            'sample': f'{nimg} images (labels 7, 14), all 10 scales + VQVAE decode, oracle/var_oracle.c via OpenMP: {dt:.1f} s'}
+            'sample': f'{nimg} images (labels 7, 14, 21, 28), all 10 scales + VQVAE decode, oracle/var_oracle.c via OpenMP: {dt:.1f} s'}
 
 
 if __name__ == '__main__':

@@ -106,14 +106,19 @@ __global__ void __launch_bounds__(256) k_dma_gemm(GemmP p) {
     // Rows past M / N are clamped to the last valid row: they only feed outputs that are never stored.
     const int drow = lane >> 3, dslot = lane & 7;
     const float* asrc[NIA]; const float* bsrc[NIB];
-    int a_b[NIA], a_y[NIA], a_x[NIA];                             // CONV: pixel of the row
+    // CONV: a_y/a_x = the row's pixel in source coordinates before the tap offset (2y, 2x for the stride-2 mode); asrc = address of
+    // that pixel's channel 0 (+ swizzle), so a tap is one scalar offset away: ((dy*Wi + dx)*Cin + ci0).  Only the nearest-2x
+    // gather mode (up2 == 1), whose source index is not linear in the tap, recomputes the full address (a_b kept for it).
+    int a_b[NIA], a_y[NIA], a_x[NIA];
 #pragma unroll
     for (int i = 0; i < NIA; ++i) {
         int m = m0 + wave * (BM / 4) + i * 8 + drow; m = m < p.M ? m : p.M - 1;
         if (CONV) {
             const int hw = p.H * p.Wd;
             a_b[i] = m / hw; const int rem2 = m - a_b[i] * hw; a_y[i] = rem2 / p.Wd; a_x[i] = rem2 - a_y[i] * p.Wd;
+            if (p.up2 == 3) { a_y[i] *= 2; a_x[i] *= 2; }
             asrc[i] = Ab + ((dslot ^ drow) << 2);
+            if (p.up2 != 1) asrc[i] += (((int64_t)a_b[i] * p.Hi + a_y[i]) * p.Wi + a_x[i]) * p.Cin;
         } else {
             asrc[i] = Ab + (int64_t)m * p.lda + ((dslot ^ drow) << 2);
         }
@@ -124,31 +129,37 @@ __global__ void __launch_bounds__(256) k_dma_gemm(GemmP p) {
         int n = n0 + wave * (BN / 4) + i * 8 + drow; n = n < p.N ? n : p.N - 1;
         bsrc[i] = Wb + (int64_t)n * p.ldw + ((dslot ^ drow) << 2);
     }
-    auto dma_tile = [&](int kt, int st) {
+    int cv_tap = 0, cv_cc = 0;                                    // CONV: tap / channel chunk of the next K tile to be requested
+    const int cv_ntap = CONV ? p.K / p.Cin : 1, cv_hlim = CONV ? (p.up2 == 3 ? p.Hi : p.H) : 0, cv_wlim = CONV ? (p.up2 == 3 ? p.Wi : p.Wd) : 0;
+    auto dma_tile = [&](int kt, int st) {                         // K tiles must be requested in order 0, 1, 2, ...
         float* sA = smem + st * STAGE + wave * (BM / 4) * BK;
         float* sB = smem + st * STAGE + BM * BK + wave * (BN / 4) * BK;
         int dy = 0, dx = 0, ci0 = 0, woff = kt * BK;
+        int64_t toff = 0;
         if (CONV) {
             // Summation order of the convolutions: 32-channel chunks outermost, then the taps, then the channels of the chunk
-            // (K tile kt = chunk kt / ntap, tap kt % ntap).  The 9 (or 4) consecutive K tiles of a chunk read the same few cache
-            // lines of the input, so the tap re-reads stay inside the XCD's L2: tap-major order moved 6.7 GB per 256x256 launch
-            // across the fabric, this order 2.4 GB (algorithmic 1.6 GB; profiles/r01_pmc_traffic.json).  Weights keep the
-            // [Cout][tap][Cin] layout: the tile's weights are the 32 floats at tap*Cin + ci0 of every row.
-            const int ntap = p.K / p.Cin, cc = kt / ntap, tap = kt - cc * ntap;
-            ci0 = cc * BK;
+            // (K tile kt = chunk kt / ntap, tap kt % ntap; the tiles are requested in order, so two counters replace the division).
+            // The 9 (or 4) consecutive K tiles of a chunk read the same few cache lines of the input, so the tap re-reads stay
+            // inside the XCD's L2: tap-major order moved 6.7 GB per 256x256 launch across the fabric, this order 2.4 GB
+            // (algorithmic 1.6 GB; profiles/r01_pmc_traffic.json).  Weights keep the [Cout][tap][Cin] layout: the tile's weights
+            // are the 32 floats at tap*Cin + ci0 of every row.
+            const int tap = cv_tap;
+            ci0 = cv_cc * BK;
             woff = tap * p.Cin + ci0;
+            if (++cv_tap == cv_ntap) { cv_tap = 0; ++cv_cc; }
             if (p.up2 == 2) { dy = (tap >> 1) - 1 + (bz >> 1); dx = (tap & 1) - 1 + (bz & 1); }   // phase (bz>>1, bz&1) of the folded Upsample2x conv
             else { const int ky = tap / 3; dy = ky - (p.up2 == 3 ? 0 : 1); dx = tap - ky * 3 - (p.up2 == 3 ? 0 : 1); }
+            toff = ((int64_t)dy * p.Wi + dx) * p.Cin + ci0;
         }
 #pragma unroll
         for (int i = 0; i < NIA; ++i) {
             const float* src;
             if (CONV) {
                 // up2: 0 plain, 1 nearest-2x gather, 2 phase conv on the low-res map, 3 stride 2 over an input zero-padded at the bottom/right
-                const int yy = (p.up2 == 3 ? 2 * a_y[i] : a_y[i]) + dy, xx = (p.up2 == 3 ? 2 * a_x[i] : a_x[i]) + dx;
-                const bool ok = yy >= 0 && xx >= 0 && (p.up2 == 3 ? (yy < p.Hi && xx < p.Wi) : (yy < p.H && xx < p.Wd));
-                const int sy = p.up2 == 1 ? (yy >> 1) : yy, sx = p.up2 == 1 ? (xx >> 1) : xx;
-                src = ok ? asrc[i] + (((int64_t)a_b[i] * p.Hi + sy) * p.Wi + sx) * p.Cin + ci0 : zsrc;
+                const int yy = a_y[i] + dy, xx = a_x[i] + dx;
+                const bool ok = (unsigned)yy < (unsigned)cv_hlim && (unsigned)xx < (unsigned)cv_wlim;
+                if (p.up2 == 1) src = ok ? asrc[i] + (((int64_t)a_b[i] * p.Hi + (yy >> 1)) * p.Wi + (xx >> 1)) * p.Cin + ci0 : zsrc;
+                else src = ok ? asrc[i] + toff : zsrc;
             } else {
                 src = asrc[i] + kt * BK;
             }
