@@ -84,7 +84,9 @@ __global__ void __launch_bounds__(256) k_dma_gemm(GemmP p) {
     constexpr int BK = 32, BM = TMW * 32, BN = TNW * 32, STAGE = (BM + BN) * BK;
     constexpr int NIA = BM / 32, NIB = BN / 32;                   // DMA instructions per wave and K tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the wave index is read into a scalar register: the LDS-DMA destination (M0) and all per-wave tile offsets then stay on the
+    // scalar unit instead of going VGPR -> v_readfirstlane -> M0 in front of every DMA instruction
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     int tm_, tn_;
     {
