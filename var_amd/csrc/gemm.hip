@@ -182,7 +182,9 @@ __global__ void __launch_bounds__(256) k_dma_gemm(GemmP p) {
 
     const int r16 = lane & 15, kq = lane >> 4;
     const int nk = p.K / BK;
-    auto compute = [&](int cur) {
+    // `mid()` (the request for the next K tile) runs after the first step's MFMAs are issued: the wave comes out of the barrier
+    // straight into LDS reads and matrix work, and the DMA address/M0 bookkeeping executes in the shadow of those MFMAs
+    auto compute = [&](int cur, auto&& mid) {
         const float* sA = smem + cur * STAGE + (wm * TMW * 16 + r16) * BK + kq;
         const float* sB = smem + cur * STAGE + BM * BK + (wn * TNW * 16 + r16) * BK + kq;
         if constexpr (TMW * TNW == 1) {
@@ -191,6 +193,7 @@ __global__ void __launch_bounds__(256) k_dma_gemm(GemmP p) {
             float a8[8], b8[8];
 #pragma unroll
             for (int s = 0; s < 8; ++s) { const int sl = (s ^ (r16 & 7)) << 2; a8[s] = sA[sl]; b8[s] = sB[sl]; }
+            mid();
 #pragma unroll
             for (int s = 0; s < 8; ++s) acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b8[s], a8[s], acc[0][0], 0, 0, 0);
             return;
@@ -219,6 +222,7 @@ __global__ void __launch_bounds__(256) k_dma_gemm(GemmP p) {
 #pragma unroll
                 for (int j = 0; j < TNW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bn[s & 1][j], am[s & 1][i], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+            if (s == 0) { mid(); __builtin_amdgcn_sched_barrier(0); }
         }
     };
     if constexpr (NST == 2) {
@@ -226,8 +230,7 @@ __global__ void __launch_bounds__(256) k_dma_gemm(GemmP p) {
         __syncthreads();                                          // includes the wait for this wave's own DMA (vmcnt)
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = kt & 1;
-            if (kt + 1 < nk) dma_tile(kt + 1, cur ^ 1);           // stage cur^1 was last read before the previous barrier
-            compute(cur);
+            compute(cur, [&] { if (kt + 1 < nk) dma_tile(kt + 1, cur ^ 1); });     // stage cur^1 was last read before the previous barrier
             __syncthreads();
         }
     } else {
@@ -243,8 +246,7 @@ __global__ void __launch_bounds__(256) k_dma_gemm(GemmP p) {
         for (int kt = 0; kt < nk; ++kt) {
             const int ahead = (nk - 1 - kt) < (NST - 2) ? (nk - 1 - kt) : (NST - 2);
             vh_wait_dma_and_barrier<NST - 2, PER>(ahead);
-            if (kt + NST - 1 < nk) dma_tile(kt + NST - 1, (kt + NST - 1) % NST);
-            compute(kt % NST);
+            compute(kt % NST, [&] { if (kt + NST - 1 < nk) dma_tile(kt + NST - 1, (kt + NST - 1) % NST); });
         }
     }
 
