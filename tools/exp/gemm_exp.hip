@@ -284,6 +284,181 @@ void run_dma(const char* name, const float* A, const float* W, float* out, int M
     printf("%-44s %4dx%-4d stages %d: %8.3f ms  %6.1f TF  mismatches vs 32x32x2 kernel %d/4096 (%s)\n", name, BM, BN, NSTAGE, best, 2.0 * M * N * K / best / 1e9, bad, hipGetErrorString(hipGetLastError()));
 }
 
+// ---- variant C: 8 waves (4 x 2), 256x128 tile, wave tile 64x64, LDS-DMA, fragment prefetch ----
+template <int MINW>
+__global__ void __launch_bounds__(512, MINW) kdma8(const float* __restrict__ A, const float* __restrict__ W, float* __restrict__ out, int M, int N, int K) {
+    constexpr int BK = 32, BM = 256, BN = 128, T = 4, STAGE = (BM + BN) * BK;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tilesN = N / BN, tilesM = M / BM;
+    int tm_, tn_;
+    {
+        const int nwg = tilesM * tilesN, bid = blockIdx.x;
+        const int q = nwg >> 3, rem = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        const int lin = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + loc;
+        const int GM = 4, width = GM * tilesN, group = lin / width, first = group * GM;
+        const int gsz = (tilesM - first) < GM ? (tilesM - first) : GM;
+        tm_ = first + (lin % width) % gsz; tn_ = (lin % width) / gsz;
+    }
+    const int m0 = tm_ * BM, n0 = tn_ * BN;
+    const int drow = lane >> 3, dslot = lane & 7;
+    const float* asrc[4]; const float* bsrc[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asrc[i] = A + (size_t)(m0 + wave * 32 + i * 8 + drow) * K + ((dslot ^ drow) << 2);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) bsrc[i] = W + (size_t)(n0 + wave * 16 + i * 8 + drow) * K + ((dslot ^ drow) << 2);
+    auto dma_tile = [&](int kt, int st) {
+        float* sA = smem + st * STAGE + wave * 32 * BK;
+        float* sB = smem + st * STAGE + BM * BK + wave * 16 * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + kt * BK), (__attribute__((address_space(3))) void*)(sA + i * 8 * BK), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[i] + kt * BK), (__attribute__((address_space(3))) void*)(sB + i * 8 * BK), 16, 0, 0);
+    };
+    f32x4v acc[T][T];
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < T; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int nk = K / BK;
+    dma_tile(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const float* sA = smem + cur * STAGE + (wm * 64 + r16) * BK + kq;
+        const float* sB = smem + cur * STAGE + BM * BK + (wn * 64 + r16) * BK + kq;
+        float af[2][T], bf[2][T];
+        { const int sl = (r16 & 7) << 2;
+#pragma unroll
+          for (int i = 0; i < T; ++i) { af[0][i] = sA[i * 16 * BK + sl]; bf[0][i] = sB[i * 16 * BK + sl]; } }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if (s + 1 < 8) { const int sl = ((s + 1) ^ (r16 & 7)) << 2;
+#pragma unroll
+                for (int i = 0; i < T; ++i) { af[(s + 1) & 1][i] = sA[i * 16 * BK + sl]; bf[(s + 1) & 1][i] = sB[i * 16 * BK + sl]; } }
+#pragma unroll
+            for (int i = 0; i < T; ++i)
+#pragma unroll
+                for (int j = 0; j < T; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[s & 1][j], af[s & 1][i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s == 0) { if (kt + 1 < nk) dma_tile(kt + 1, cur ^ 1); __builtin_amdgcn_sched_barrier(0); }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < T; ++j)
+            *(f32x4v*)(out + (size_t)(m0 + wm * 64 + i * 16 + r16) * N + n0 + wn * 64 + j * 16 + kq * 4) = acc[i][j];
+}
+template <int MINW>
+void run_dma8(const char* name, const float* A, const float* W, float* out, int M, int N, int K) {
+    size_t lds = (size_t)2 * (256 + 128) * 32 * 4;
+    auto kf = kdma8<MINW>;
+    hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid((M / 256) * (N / 128));
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9;
+    for (int rep = 0; rep < 4; ++rep) {
+        hipEventRecord(e0);
+        for (int it = 0; it < 3; ++it) hipLaunchKernelGGL(kf, grid, dim3(512), lds, 0, A, W, out, M, N, K);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 3; if (ms < best) best = ms;
+    }
+    printf("%-44s 256x128 8 waves: %8.3f ms  %6.1f TF (%s)\n", name, best, 2.0 * M * N * K / best / 1e9, hipGetErrorString(hipGetLastError()));
+}
+
+// ---- variant D: one wave per workgroup, 64x64 tile, private LDS stages, NO barriers (only the wave's own vmcnt waits) ----
+template <int N_> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
+template <int NST>
+__global__ void __launch_bounds__(64) kwave(const float* __restrict__ A, const float* __restrict__ W, float* __restrict__ out, int M, int N, int K) {
+    constexpr int BK = 32, BM = 64, BN = 64, T = 4, STAGE = (BM + BN) * BK;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x;
+    const int tilesN = N / BN, tilesM = M / BM;
+    int tm_, tn_;
+    {
+        const int nwg = tilesM * tilesN, bid = blockIdx.x;
+        const int q = nwg >> 3, rem = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        const int lin = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + loc;
+        const int GM = 16, width = GM * tilesN, group = lin / width, first = group * GM;
+        const int gsz = (tilesM - first) < GM ? (tilesM - first) : GM;
+        tm_ = first + (lin % width) % gsz; tn_ = (lin % width) / gsz;
+    }
+    const int m0 = tm_ * BM, n0 = tn_ * BN;
+    const int drow = lane >> 3, dslot = lane & 7;
+    const float* asrc[8]; const float* bsrc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { asrc[i] = A + (size_t)(m0 + i * 8 + drow) * K + ((dslot ^ drow) << 2); bsrc[i] = W + (size_t)(n0 + i * 8 + drow) * K + ((dslot ^ drow) << 2); }
+    auto dma_tile = [&](int kt, int st) {
+        float* sA = smem + st * STAGE; float* sB = sA + BM * BK;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + kt * BK), (__attribute__((address_space(3))) void*)(sA + i * 8 * BK), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[i] + kt * BK), (__attribute__((address_space(3))) void*)(sB + i * 8 * BK), 16, 0, 0);
+    };
+    f32x4v acc[T][T];
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < T; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int nk = K / BK;
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t) if (t < nk) dma_tile(t, t);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt % NST;
+        // tile kt landed when at most (NST-2) later tiles (16 instrs each) are outstanding
+        const int ahead = (nk - 1 - kt) < (NST - 2) ? (nk - 1 - kt) : (NST - 2);
+        if (NST >= 3 && ahead >= 1) wait_vm<16>(); else wait_vm<0>();
+        const float* sA = smem + cur * STAGE + r16 * BK + kq;
+        const float* sB = smem + cur * STAGE + BM * BK + r16 * BK + kq;
+        float af[2][T], bf[2][T];
+        { const int sl = (r16 & 7) << 2;
+#pragma unroll
+          for (int i = 0; i < T; ++i) { af[0][i] = sA[i * 16 * BK + sl]; bf[0][i] = sB[i * 16 * BK + sl]; } }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if (s + 1 < 8) { const int sl = ((s + 1) ^ (r16 & 7)) << 2;
+#pragma unroll
+                for (int i = 0; i < T; ++i) { af[(s + 1) & 1][i] = sA[i * 16 * BK + sl]; bf[(s + 1) & 1][i] = sB[i * 16 * BK + sl]; } }
+#pragma unroll
+            for (int i = 0; i < T; ++i)
+#pragma unroll
+                for (int j = 0; j < T; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[s & 1][j], af[s & 1][i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // the stage of tile kt-1 is free once this wave's reads of it are done: they were, before this tile's first MFMA
+            if (s == 0) { if (kt + NST - 1 < nk) dma_tile(kt + NST - 1, (kt + NST - 1) % NST); __builtin_amdgcn_sched_barrier(0); }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < T; ++j)
+            *(f32x4v*)(out + (size_t)(m0 + i * 16 + r16) * N + n0 + j * 16 + kq * 4) = acc[i][j];
+}
+template <int NST>
+void run_wave(const char* name, const float* A, const float* W, float* out, int M, int N, int K, const float* ref) {
+    size_t lds = (size_t)NST * 128 * 32 * 4;
+    auto kf = kwave<NST>;
+    hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid((M / 64) * (N / 64));
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9;
+    for (int rep = 0; rep < 4; ++rep) {
+        hipEventRecord(e0);
+        for (int it = 0; it < 3; ++it) hipLaunchKernelGGL(kf, grid, dim3(64), lds, 0, A, W, out, M, N, K);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 3; if (ms < best) best = ms;
+    }
+    std::vector<float> a(4096), b(4096);
+    hipMemcpy(a.data(), out, 4096 * 4, hipMemcpyDeviceToHost); hipMemcpy(b.data(), ref, 4096 * 4, hipMemcpyDeviceToHost);
+    int bad = 0; for (int i = 0; i < 4096; ++i) bad += (a[i] != b[i]);
+    printf("%-44s 64x64 1 wave/WG %d stages: %8.3f ms  %6.1f TF  mismatches %d (%s)\n", name, NST, best, 2.0 * M * N * K / best / 1e9, bad, hipGetErrorString(hipGetLastError()));
+}
+
 int main(int argc, char** argv) {
     int M = argc > 1 ? atoi(argv[1]) : 8192, N = argc > 2 ? atoi(argv[2]) : 8192, K = argc > 3 ? atoi(argv[3]) : 4096;
     float *A, *W, *out;
@@ -301,5 +476,8 @@ int main(int argc, char** argv) {
     run_dma<32, 2, 32, 1>("DMA 64x64 BK32 2 stages", A, W, out, M, N, K, ref);
     run_dma<32, 2, 32, 1, 1>("DMA 64x64 BK32 2 stages frag-prefetch", A, W, out, M, N, K, ref);
     run_dma<32, 2, 32, 1, 2>("DMA 64x64 BK32 2 stages frag-prefetch+schedbar", A, W, out, M, N, K, ref);
+    run_dma8<1>("DMA 256x128 8 waves", A, W, out, M, N, K);
+    run_wave<2>("one wave per WG", A, W, out, M, N, K, ref);
+    run_wave<3>("one wave per WG", A, W, out, M, N, K, ref);
     return 0;
 }
