@@ -184,6 +184,9 @@ __global__ void __launch_bounds__(256) k_dma_gemm(GemmP p) {
     const int nk = p.K / BK;
     // `mid()` (the request for the next K tile) runs after the first step's MFMAs are issued: the wave comes out of the barrier
     // straight into LDS reads and matrix work, and the DMA address/M0 bookkeeping executes in the shadow of those MFMAs
+    // a wave whose whole column range lies past N (the 160 -> 3 output conv has N = 3 in a 32-wide tile, so half the waves) or whose
+    // rows lie past M only keeps up the DMA requests and the barriers; its SIMD's matrix time goes to the other workgroups on the CU
+    const bool idle_wave = (n0 + wn * TNW * 16 >= p.N) || (m0 + wm * TMW * 16 >= p.M);
     auto compute = [&](int cur, auto&& mid) {
         const float* sA = smem + cur * STAGE + (wm * TMW * 16 + r16) * BK + kq;
         const float* sB = smem + cur * STAGE + BM * BK + (wn * TNW * 16 + r16) * BK + kq;
@@ -228,6 +231,9 @@ __global__ void __launch_bounds__(256) k_dma_gemm(GemmP p) {
     if constexpr (NST == 2) {
         dma_tile(0, 0);
         __syncthreads();                                          // includes the wait for this wave's own DMA (vmcnt)
+        if (idle_wave) {                                          // same requests and barriers, no matrix work (kept out of the hot loop)
+            for (int kt = 0; kt < nk; ++kt) { if (kt + 1 < nk) dma_tile(kt + 1, (kt & 1) ^ 1); __syncthreads(); }
+        } else
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = kt & 1;
             compute(cur, [&] { if (kt + 1 < nk) dma_tile(kt + 1, cur ^ 1); });     // stage cur^1 was last read before the previous barrier
