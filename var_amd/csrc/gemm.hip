@@ -436,7 +436,8 @@ extern "C" int varhip_gemm_nt_f32(const float* A, int64_t lda, const float* W, i
     // for block-count quantisation: cost ~ ceil(blocks / 256 CUs) * tile area / relative tile efficiency; pick the cheapest.
     auto cost = [&](int bm, int bn, double eff) {
         const int64_t nb = (int64_t)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch;
-        return (double)((nb + 255) / 256) * bm * bn / eff;
+        // a workgroup alone on its CU (nb <= 256) has no co-resident partner to cover its barrier waits: ~10 % slower (measured)
+        return (double)((nb + 255) / 256) * bm * bn / (nb <= 256 ? 0.9 * eff : eff);
     };
     const double c128 = cost(128, 128, 1.0), c12864 = cost(128, 64, 0.97), c64 = cost(64, 64, 0.93);
     int pick = !vec ? 3 : (c128 <= c12864 && c128 <= c64) ? 0 : (c12864 <= c64 ? 1 : 2);
