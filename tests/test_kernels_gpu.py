@@ -79,6 +79,25 @@ def test_gemm_exact(M, N, K, epi):
     check(f'gemm {M}x{N}x{K} epi{epi}', g, w)
 
 
+def test_gemm_random_shapes_exact():
+    """30 seeded random shapes around the tile edges (ragged M and N, K on and off the 32-multiple fast path, every epilogue):
+    every tile configuration, idle waves, the element-wise epilogue and the fallback kernel against the oracle, bit for bit"""
+    rs = np.random.default_rng(20240)
+    for case in range(30):
+        M = int(rs.choice([1, 2, 15, 16, 17, 31, 33, 63, 64, 65, 127, 129, 255, 300, 513, 700]))
+        N = int(rs.choice([1, 3, 4, 8, 15, 16, 20, 33, 60, 64, 68, 100, 128, 132, 260, 516]))
+        K = int(rs.choice([32, 64, 96, 160, 256, 1024, 40, 7, 100]))
+        epi = int(rs.integers(0, 3))
+        rng = np.random.default_rng(case)
+        A, W, bias = rnd(rng, M, K), rnd(rng, N, K, scale=0.05), rnd(rng, N, scale=0.1)
+        resid = rnd(rng, M, N); rpg = int(rs.integers(1, M + 1)); G = (M + rpg - 1) // rpg
+        gamma = rnd(rng, G, N)
+        out = np.zeros((M, N), np.float32)
+        args = [A, K, W, K, bias if case % 5 else None, out, N, M, N, K, epi, resid if epi == 2 else None, N, gamma if (epi == 2 and case % 3) else None, N, rpg, 0, 1, 0, 0, 0]
+        (g,), (w,) = both('gemm_nt_f32', args, [5])
+        check(f'gemm random #{case} {M}x{N}x{K} epi{epi}', g, w)
+
+
 def test_gemm_batched_bias_per_row_and_shared_operand():
     rng = np.random.default_rng(5)
     Bt, M, N, K = 3, 96, 256, 64                    # V^T = Wv . x^T per sample: A shared (sA = 0), W per sample
@@ -198,6 +217,21 @@ def test_attn_cached_exact(B2, l, H, curL, Lmax):
     out = np.zeros((B2 * l, C), np.float32)
     (g,), (w,) = both('attn_cached_f32', [q, kc, vc, out, B2, l, H, curL, Lmax], [3])
     check(f'attn l={l} curL={curL}', g, w)
+
+
+def test_attn_random_ragged_shapes_exact():
+    """12 seeded random (l, curL) pairs off the 32/128 tile edges, wide score ranges included"""
+    rs = np.random.default_rng(77)
+    for case in range(12):
+        l = int(rs.choice([1, 2, 5, 31, 32, 33, 63, 65, 100, 127, 129, 169, 200]))
+        curL = l + int(rs.choice([0, 1, 14, 31, 32, 33, 100, 255]))
+        B2, H = int(rs.integers(1, 4)), int(rs.integers(1, 4))
+        rng = np.random.default_rng(1000 + case)
+        q = rnd(rng, B2 * l, 64 * H, scale=float(rs.choice([0.3, 1.0, 4.0])))
+        kc = rnd(rng, B2, H, curL, 64, scale=0.7); vc = rnd(rng, B2, H, curL, 64)
+        out = np.zeros((B2 * l, 64 * H), np.float32)
+        (g,), (w,) = both('attn_cached_f32', [q, kc, vc, out, B2, l, H, curL, curL], [3])
+        check(f'attn random #{case} l={l} curL={curL} B2={B2} H={H}', g, w)
 
 
 def test_attn_peaked_rows():
