@@ -406,6 +406,29 @@ def test_conv3x3_exact(B, H, W, Cin, Cout, up2, resid, mode):
     check(f'conv3x3 {Cin}->{Cout} {H}x{W} up{up2} mode{mode}', g, wv)
 
 
+def test_conv3x3_random_shapes_exact():
+    """16 seeded random convolutions: ragged images (pixel counts off the 128-row tile), channel counts off the 16/32-wide tiles,
+    all input modes (plain, nearest-2x gather, stride 2), residual on and off, the NCHW clamp/denorm output"""
+    rs = np.random.default_rng(4242)
+    for case in range(16):
+        B = int(rs.integers(1, 4)); H = int(rs.choice([2, 4, 6, 10, 16, 22])); W = int(rs.choice([2, 4, 8, 14, 16, 30]))
+        Cin = int(rs.choice([32, 64, 96, 160])); Cout = int(rs.choice([1, 3, 5, 16, 20, 33, 64, 100, 160]))
+        kind = int(rs.integers(0, 4))                   # 0 plain, 1 gather, 2 stride-2, 3 NCHW clamp output
+        rng = np.random.default_rng(500 + case)
+        w = rnd(rng, Cout, 3, 3, Cin, scale=(1.0 / (9 * Cin)) ** 0.5); bias = rnd(rng, Cout, scale=0.1)
+        if kind == 2:
+            x = rnd(rng, B, 2 * H, 2 * W, Cin); out = np.zeros((B, H, W, Cout), np.float32)
+            (g,), (wv,) = both('conv3x3_s2_nhwc_f32', [x, w, bias, out, B, H, W, Cin, Cout], [3])
+        else:
+            up2 = 1 if kind == 1 else 0
+            x = rnd(rng, B, H // 2 if up2 else H, W // 2 if up2 else W, Cin)
+            mode = int(rs.integers(1, 3)) if kind == 3 else 0
+            res = rnd(rng, B, H, W, Cout) if (mode == 0 and case % 2) else None
+            out = np.zeros((B, Cout, H, W) if mode else (B, H, W, Cout), np.float32)
+            (g,), (wv,) = both('conv3x3_nhwc_f32', [x, w, bias, res, out, B, H, W, Cin, Cout, up2, mode], [4])
+        check(f'conv random #{case} kind{kind} {Cin}->{Cout} {H}x{W} B{B}', g, wv)
+
+
 @pytest.mark.parametrize('B,H,W,Cin,Cout', [(2, 6, 6, 32, 32), (1, 32, 32, 640, 640), (2, 64, 48, 160, 160), (1, 16, 16, 64, 128)])
 def test_upconv_phase(B, H, W, Cin, Cout):
     """Upsample2x as four 2x2 phase convs: bit-exact vs its CPU twin, and equal to the plain nearest-2x + 3x3 conv up to the
