@@ -284,6 +284,24 @@ def test_cfg_sample_tie_crowd_beyond_sort_buffer(V, top_k, top_p, n_above, n_tie
         assert np.isfinite(wm).sum(axis=1).min() >= 1
 
 
+def test_cfg_sample_random_quantised_logits_exact():
+    """14 seeded random sampler configurations on logits rounded to a coarse grid (exact ties everywhere: at the top-k threshold,
+    inside the top-p walk, at the arg-max), several vocabulary sizes, t != 0 so the CFG combine creates the ties' values"""
+    rs = np.random.default_rng(99)
+    for case in range(14):
+        V = int(rs.choice([256, 512, 768, 1024, 4096])); B = int(rs.integers(1, 3)); l = int(rs.integers(1, 6))
+        top_k = int(rs.choice([0, 1, 7, 100, 255, V // 2, V])); top_p = float(rs.choice([0.0, 0.1, 0.5, 0.9, 0.96, 0.9999]))
+        grid = float(rs.choice([0.5, 0.125, 1.0]))
+        rng = np.random.default_rng(3000 + case)
+        logits = (np.round(rnd(rng, 2 * B * l, V, scale=2.0) / grid) * grid).astype(np.float32)
+        noise = rng.exponential(1.0, (B * l, V)).astype(np.float32)
+        idx = np.zeros(B * l, np.int64); masked = np.zeros((B * l, V), np.float32)
+        (gi, gm), (wi, wm) = both('cfg_sample_f32', [logits, noise, idx, masked, B, l, V, 0.5, top_k, top_p], [2, 3])
+        check(f'sampler random #{case} V={V} k={top_k} p={top_p} kept-set', np.isfinite(gm), np.isfinite(wm))
+        check(f'sampler random #{case} masked', gm, wm)
+        check(f'sampler random #{case} tokens', gi, wi)
+
+
 def test_cfg_sample_ties_and_golden(golden_dir):
     """rows full of exact ties, and the reference's own sampler fixtures (tests/golden/sampler.npz) straight through the HIP kernel"""
     import json
