@@ -233,11 +233,17 @@ __global__ void __launch_bounds__(256) k_dma_gemm(GemmP p) {
         __syncthreads();                                          // includes the wait for this wave's own DMA (vmcnt)
         if (idle_wave) {                                          // same requests and barriers, no matrix work (kept out of the hot loop)
             for (int kt = 0; kt < nk; ++kt) { if (kt + 1 < nk) dma_tile(kt + 1, (kt & 1) ^ 1); __syncthreads(); }
-        } else
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-            compute(cur, [&] { if (kt + 1 < nk) dma_tile(kt + 1, cur ^ 1); });     // stage cur^1 was last read before the previous barrier
-            __syncthreads();
+        } else {
+            // two K tiles per trip, so the LDS stage is a compile-time constant in each copy of the tile body: the operand reads
+            // then take their stage/tile offsets as instruction immediates instead of one v_add per read
+            int kt = 0;
+            for (; kt + 1 < nk; kt += 2) {
+                compute(0, [&] { dma_tile(kt + 1, 1); });                  // stage 1 was last read before the previous barrier
+                __syncthreads();
+                compute(1, [&] { if (kt + 2 < nk) dma_tile(kt + 2, 0); });
+                __syncthreads();
+            }
+            if (kt < nk) { compute(0, [] {}); __syncthreads(); }           // odd tile count: the last tile sits in stage 0
         }
     } else {
         // Deep pipeline for launches with fewer workgroups than CUs (small scales): NST-1 tiles in flight, so the K loop of the
