@@ -79,7 +79,9 @@ template <int MAXA, int PER> __device__ __forceinline__ void vh_wait_dma_and_bar
     else { if (ahead >= MAXA) vh_waitcnt_barrier<MAXA * PER>(); else vh_wait_dma_and_barrier<MAXA - 1, PER>(ahead); }
 }
 
-template <int TMW, int TNW, bool CONV, int NST = 2>
+// GATHER: the nearest-2x gather mode of the convolution (up2 == 1; tests and the oracle comparison only — the decoder runs the
+// phase form), kept out of the common kernels so that their tap address stays two adds and a select
+template <int TMW, int TNW, bool CONV, int NST = 2, bool GATHER = false>
 __global__ void __launch_bounds__(256) k_dma_gemm(GemmP p) {
     constexpr int BK = 32, BM = TMW * 32, BN = TNW * 32, STAGE = (BM + BN) * BK;
     constexpr int NIA = BM / 32, NIB = BN / 32;                   // DMA instructions per wave and K tile
@@ -120,7 +122,7 @@ __global__ void __launch_bounds__(256) k_dma_gemm(GemmP p) {
             a_b[i] = m / hw; const int rem2 = m - a_b[i] * hw; a_y[i] = rem2 / p.Wd; a_x[i] = rem2 - a_y[i] * p.Wd;
             if (p.up2 == 3) { a_y[i] *= 2; a_x[i] *= 2; }
             asrc[i] = Ab + ((dslot ^ drow) << 2);
-            if (p.up2 != 1) asrc[i] += (((int64_t)a_b[i] * p.Hi + a_y[i]) * p.Wi + a_x[i]) * p.Cin;
+            if (!GATHER) asrc[i] += (((int64_t)a_b[i] * p.Hi + a_y[i]) * p.Wi + a_x[i]) * p.Cin;
         } else {
             asrc[i] = Ab + (int64_t)m * p.lda + ((dslot ^ drow) << 2);
         }
@@ -160,7 +162,7 @@ __global__ void __launch_bounds__(256) k_dma_gemm(GemmP p) {
                 // up2: 0 plain, 1 nearest-2x gather, 2 phase conv on the low-res map, 3 stride 2 over an input zero-padded at the bottom/right
                 const int yy = a_y[i] + dy, xx = a_x[i] + dx;
                 const bool ok = (unsigned)yy < (unsigned)cv_hlim && (unsigned)xx < (unsigned)cv_wlim;
-                if (p.up2 == 1) src = ok ? asrc[i] + (((int64_t)a_b[i] * p.Hi + (yy >> 1)) * p.Wi + (xx >> 1)) * p.Cin + ci0 : zsrc;
+                if (GATHER) src = ok ? asrc[i] + (((int64_t)a_b[i] * p.Hi + (yy >> 1)) * p.Wi + (xx >> 1)) * p.Cin + ci0 : zsrc;
                 else src = ok ? asrc[i] + toff : zsrc;
             } else {
                 src = asrc[i] + kt * BK;
@@ -401,12 +403,12 @@ __global__ void __launch_bounds__(256) k_dma_gemm(GemmP p) {
     }
 }
 
-template <int TMW, int TNW, bool CONV = false, int NST = 2>
+template <int TMW, int TNW, bool CONV = false, int NST = 2, bool GATHER = false>
 static int launch_dma(GemmP& p, int batch, hipStream_t stream) {
     constexpr int BM = TMW * 32, BN = TNW * 32;
     constexpr size_t lds = NST * (size_t)(BM + BN) * 32 * sizeof(float);
     p.tilesM = (p.M + BM - 1) / BM; p.tilesN = (p.N + BN - 1) / BN;
-    auto kfn = k_dma_gemm<TMW, TNW, CONV, NST>;
+    auto kfn = k_dma_gemm<TMW, TNW, CONV, NST, GATHER>;
     static bool attr_done = false;
     if (!attr_done) {
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -467,6 +469,11 @@ extern "C" int varhip_gemm_nt_f32(const float* A, int64_t lda, const float* W, i
 // tile choice of the implicit-GEMM convolutions: the N tile divides Cout (160/320/640 -> 160 wide); Cin % 32 == 0 so that a
 // K tile of 32 lies inside one tap
 static int launch_conv(GemmP& p, int batch, hipStream_t s) {
+    if (p.up2 == 1) {                                                 // nearest-2x gather (not on the hot path)
+        if (p.N % 160 == 0) return launch_dma<4, 5, true, 2, true>(p, batch, s);
+        if (p.N % 64 == 0) return launch_dma<4, 2, true, 2, true>(p, batch, s);
+        return launch_dma<4, 1, true, 2, true>(p, batch, s);
+    }
     if (p.N % 160 == 0) return launch_dma<4, 5, true>(p, batch, s);     // (64x160 tiles were measured: 6 % slower)
     if (p.N % 128 == 0) return launch_dma<4, 4, true>(p, batch, s);
     if (p.N % 64 == 0) return launch_dma<4, 2, true>(p, batch, s);
