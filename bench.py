@@ -97,7 +97,7 @@ def main():
         fam = max(('gemm', 'conv3x3', 'attn'), key=lambda k: tt[k]['ms'] * (1.05 if k == 'gemm' else 1.0)) if args.kernel_breakdown else 'gemm'
         f = tt[fam]
         achieved = f['flops'] / (f['ms'] * 1e-3) / 1e12 if f['ms'] > 0 else 0.0
-        kname = {'gemm': 'k_dma_gemm<4,4,false,2>', 'conv3x3': 'k_dma_gemm<4,5,true,2>', 'attn': 'k_attn_cached'}[fam]
+        kname = {'gemm': 'k_dma_gemm<4,4,false,2,false>', 'conv3x3': 'k_dma_gemm<4,5,true,2,false>', 'attn': 'k_attn_cached'}[fam]
         traffic = None                                                       # HBM-side bytes per launch from a separate rocprofv3 --pmc pass
         try:
             pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))['kernels'].get(kname)
