@@ -64,6 +64,7 @@ class _VaeOps:
         self.vae = vae
         self._sig = None
         self.w: Dict[str, torch.Tensor] = {}
+        self._gn_part = None            # (tensor, partial sums, blocks per sample) left by the last conv for the GroupNorm after it
 
     def _signature(self):
         return tuple((p.data_ptr(), p._version) for p in self.vae.parameters())
@@ -132,7 +133,7 @@ class DecoderEngine(_VaeOps):
     def gn(self, x, key, B, HW, silu):
         Cc = x.shape[-1]
         stats = torch.empty((B, 32, 2), dtype=torch.float32, device=x.device)
-        pend = getattr(self, '_gn_part', None)
+        pend = self._gn_part
         self._gn_part = None
         if pend is not None and pend[0].data_ptr() == x.data_ptr() and pend[0].numel() == x.numel() and tuple(pend[1].shape) == (B, pend[2], Cc, 2):
             hip.call('gn_stats_part_f32', pend[1], stats, B, pend[2], HW, Cc, 32, 1e-6)
