@@ -119,6 +119,7 @@ def main():
             'kernel_time_ms_per_step': {k: round(v['ms'] / args.steps, 3) for k, v in tt.items() if v['launches'] > 0},
             'kernel_tflops': {k: round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2) for k, v in tt.items() if v['ms'] > 0 and v['flops'] > 0},
             'kernel_algorithmic_gbps': {k: round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1) for k, v in tt.items() if v['ms'] > 0 and v['bytes'] > 0},
+            'peak_hbm_allocated_gib': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
             'whole_path': {'gflop_per_image': round((flops_img + dec_flops_img) / 1e9, 1),
                            'tflops': round(ips * (flops_img + dec_flops_img) / 1e12 / world, 2),
                            'frac_of_f32_mfma_peak': round(ips * (flops_img + dec_flops_img) / 1e12 / world / PEAK_F32_MFMA_TFLOPS, 4)},
