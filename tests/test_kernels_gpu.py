@@ -66,6 +66,27 @@ def test_library_loads_and_reports_version():
     assert torch.cuda.is_available()
 
 
+def test_timing_table_counts_only_the_selected_families():
+    """bench.py's roofline numbers come from this table: launches, algorithmic FLOPs and event time per kernel family, restricted
+    to the families asked for (every timed launch costs two event records)"""
+    _, hip = _setup()
+    a = torch.randn(256, 128, device='cuda'); w = torch.randn(256, 128, device='cuda'); o = torch.empty(256, 256, device='cuda')
+    x = torch.randn(1 << 16, device='cuda'); y = torch.empty_like(x)
+    def work():
+        for _ in range(3):
+            hip.call('gemm_nt_f32', a, 128, w, 128, None, o, 256, 256, 256, 128, 0, None, 0, None, 0, 1, 0, 1, 0, 0, 0)
+            hip.call('silu_f32', x, y, x.numel())
+    hip.timing_reset(); hip.timing_enable(True); work(); hip.timing_enable(False)
+    t = hip.timing_read()
+    small = t['gemm_small']
+    assert small['launches'] == 3 and small['flops'] == 3 * 2.0 * 256 * 256 * 128 and small['ms'] > 0 and t['other']['launches'] == 3
+    hip.timing_reset(); hip.timing_enable(True, ['other']); work(); hip.timing_enable(False)
+    t = hip.timing_read()
+    assert t['other']['launches'] == 3 and t['gemm_small']['launches'] == 0 and t['gemm']['launches'] == 0
+    hip.timing_reset(); hip.timing_enable(False, None); work()
+    assert all(v['launches'] == 0 for v in hip.timing_read().values())
+
+
 @pytest.mark.parametrize('M,N,K', [(128, 128, 128), (4, 384, 128), (36, 512, 128), (300, 320, 640), (1152, 1024, 1024), (2048, 3072, 1024), (64, 4096, 256), (1, 128, 32), (130, 40, 8), (9, 128, 9), (25, 33, 25), (70, 70, 13), (70, 50, 64), (3, 52, 96), (200, 17, 32)])
 @pytest.mark.parametrize('epi', [0, 1, 2])
 def test_gemm_exact(M, N, K, epi):
