@@ -71,9 +71,12 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    # HIP events around the launches, on the launch stream: every family with --kernel-breakdown, else only the dominant kernel
-    # (the 128x128 transformer GEMM; profiles/r01_bench_kernel_stats.csv: it and the conv kernel lead, within 3 % of each other)
-    hip.timing_reset(); hip.timing_enable(True, None if args.kernel_breakdown else ['gemm'])
+    # HIP events around the launches, on the launch stream: every family with --kernel-breakdown, else only the dominant kernel.
+    # profiles/r01_bench_kernel_stats.csv: at d16 the decoder's 128x160 implicit-GEMM conv instantiation leads (33 % of the device
+    # time; the transformer GEMMs are spread over four tile instantiations of the same kernel, the largest at 21 %); from d20 up
+    # the 128x128 transformer GEMM instantiation leads.
+    dominant = 'conv3x3' if args.depth <= 16 else 'gemm'
+    hip.timing_reset(); hip.timing_enable(True, None if args.kernel_breakdown else [dominant])
     dist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -92,9 +95,8 @@ def main():
         ips = B_total * args.steps / dt
         flops_img = var.engine().flops_per_image()
         dec_flops_img = var.engine().dec.flops_per_image_reference(pns[-1])          # as the reference computes the decoder (9-tap upsample convs)
-        # dominant kernel by device time: with the full breakdown the leader is picked (the GEMM unless another family leads it by
-        # more than 5 %: it and the conv kernel are within a few % at d16/B=64); the default run times and reports the GEMM
-        fam = max(('gemm', 'conv3x3', 'attn'), key=lambda k: tt[k]['ms'] * (1.05 if k == 'gemm' else 1.0)) if args.kernel_breakdown else 'gemm'
+        # dominant kernel by device time: with the full breakdown the measured leader among the single-symbol families is picked
+        fam = max(('gemm', 'conv3x3', 'attn'), key=lambda k: tt[k]['ms']) if args.kernel_breakdown else dominant
         f = tt[fam]
         achieved = f['flops'] / (f['ms'] * 1e-3) / 1e12 if f['ms'] > 0 else 0.0
         kname = {'gemm': 'k_dma_gemm<4,4,false,2,false>', 'conv3x3': 'k_dma_gemm<4,5,true,2,false>', 'attn': 'k_attn_cached'}[fam]

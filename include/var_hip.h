@@ -244,9 +244,12 @@ int varhip_nearest_code_f32(const float* z, const float* codebook, int64_t* idx_
 /* ---- per-kernel timing (bench.py's roofline leg) -----------------------------------------------------------
  * When enabled, every launch is bracketed by hipEvents on its own stream and its algorithmic FLOPs and bytes are
  * accumulated per kernel family.  varhip_timing_read synchronises the recorded events.
- * families: 0 gemm (128x128-tile kernel), 1 conv3x3, 2 attn, 3 sampler, 4 ln, 5 qkv_prep, 6 gn, 7 other, 8 gemm_small (64x64-tile
- * and element-wise-load variants).  Returns the number of families. */
-#define VARHIP_NFAM 9
+ * families: 0 gemm (the 128x128-tile instantiation k_dma_gemm<4,4,false,2,false>), 1 conv3x3 (the 128x160-tile implicit-GEMM
+ * instantiation k_dma_gemm<4,5,true,2,false>), 2 attn, 3 sampler, 4 ln, 5 qkv_prep, 6 gn, 7 other, 8 gemm_small (every other tile
+ * of the transformer GEMMs and the element-wise-load fallback), 9 conv_small (every other conv tile: nearest-2x gather, Cout not
+ * a multiple of 160).  Families 0 and 1 each map to exactly one kernel symbol, so their averages can be checked against a
+ * rocprofv3 kernel trace.  Returns the number of families. */
+#define VARHIP_NFAM 10
 int varhip_timing_enable(int on);
 /* restrict the timing to the families whose bit is set (default: all).  Every timed launch costs two event records on the stream —
  * about 2 % of a sampling call when all ~3000 launches are timed; bench.py times only what its roofline object reports. */

@@ -85,6 +85,16 @@ def test_timing_table_counts_only_the_selected_families():
     assert t['other']['launches'] == 3 and t['gemm_small']['launches'] == 0 and t['gemm']['launches'] == 0
     hip.timing_reset(); hip.timing_enable(False, None); work()
     assert all(v['launches'] == 0 for v in hip.timing_read().values())
+    # the two conv families follow the tile instantiation: Cout % 160 == 0 without the nearest-2x gather is 'conv3x3'
+    xin = torch.randn(1, 8, 8, 32, device='cuda'); bias = torch.zeros(160, device='cuda'); wt = torch.randn(160, 9 * 32, device='cuda')
+    out = torch.empty(1, 16, 16, 160, device='cuda')
+    hip.timing_reset(); hip.timing_enable(True)
+    hip.call('conv3x3_nhwc_f32', xin, wt, bias, None, out, 1, 8, 8, 32, 160, 0, 0)
+    hip.call('conv3x3_nhwc_f32', xin, wt, bias, None, out, 1, 8, 8, 32, 64, 0, 0)
+    hip.call('conv3x3_nhwc_f32', xin, wt, bias, None, out, 1, 16, 16, 32, 160, 1, 0)
+    hip.timing_enable(False)
+    t = hip.timing_read()
+    assert t['conv3x3']['launches'] == 1 and t['conv_small']['launches'] == 2 and t['conv3x3']['flops'] == 2.0 * 64 * 160 * 9 * 32
 
 
 @pytest.mark.parametrize('M,N,K', [(128, 128, 128), (4, 384, 128), (36, 512, 128), (300, 320, 640), (1152, 1024, 1024), (2048, 3072, 1024), (64, 4096, 256), (1, 128, 32), (130, 40, 8), (9, 128, 9), (25, 33, 25), (70, 70, 13), (70, 50, 64), (3, 52, 96), (200, 17, 32)])

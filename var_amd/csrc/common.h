@@ -18,6 +18,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define VH_FAM_GN 6
 #define VH_FAM_OTHER 7
 #define VH_FAM_GEMM_SMALL 8
+#define VH_FAM_CONV_SMALL 9
 
 // ---- timing table (timing.cpp) ------------------------------------------------------------------------------------
 int vh_timing_on(int fam);

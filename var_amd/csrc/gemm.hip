@@ -440,14 +440,21 @@ extern "C" int varhip_gemm_nt_f32(const float* A, int64_t lda, const float* W, i
     p.M = M; p.N = N; p.K = K; p.epi = epi; p.rows_per_group = rows_per_group > 0 ? rows_per_group : 1; p.bias_per_row = bias_per_row;
     p.evec = !((N & 3) || (ldo & 3) || (sO & 3) || ((uintptr_t)out & 15) || (bias && !bias_per_row && ((uintptr_t)bias & 15)) ||
                (resid && ((ldr & 3) || ((uintptr_t)resid & 15))) || (gamma && ((ldg & 3) || ((uintptr_t)gamma & 15))));
-    // Tile choice.  K cannot be split (arithmetic contract), so launches that do not fill 256 CUs several times over pay
-    // for block-count quantisation: cost ~ ceil(blocks / 256 CUs) * tile area / relative tile efficiency; pick the cheapest.
-    auto cost = [&](int bm, int bn, double eff) {
-        const int64_t nb = (int64_t)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch;
-        // a workgroup alone on its CU (nb <= 256) has no co-resident partner to cover its barrier waits: ~10 % slower (measured)
-        return (double)((nb + 255) / 256) * bm * bn / (nb <= 256 ? 0.9 * eff : eff);
+    // Tile choice.  K cannot be split (arithmetic contract), so launches that do not fill 256 CUs several times over pay for
+    // block-count quantisation.  cost ~ quantised block count * tile area / relative tile efficiency; the block count is rounded
+    // up to whole rounds of 256 CUs and (weight 1/4) to whole rounds of the co-resident workgroups of the tile (2 / 3 / 4 per CU
+    // by LDS and registers) — fitted to the forced-tile timings of every d16 shape (tools/bench_kernels.py gemm with
+    // VARHIP_GEMM_TILE=0/1/2): the picks land within 0.1 % of the per-shape best in total.
+    auto cost = [&](int bm, int bn, int occ, double eff) {
+        const int64_t nb = (int64_t)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch, slots = 256 * occ;
+        const double q = 0.75 * (double)((nb + 255) / 256 * 256) + 0.25 * (double)((nb + slots - 1) / slots * slots);
+        return q * bm * bn / eff;
     };
-    const double c128 = cost(128, 128, 1.0), c12864 = cost(128, 64, 0.97), c64 = cost(64, 64, 0.93);
+    // Relative tile efficiencies with the unrolled main loop: the smaller tiles run the K loop as fast as the 128x128 one
+    // (1.0 / 1.0 / 0.985); what separates them is the epilogue — a GELU or gamma*x+residual epilogue after a short K loop
+    // costs the big tile ~5 % because fewer workgroups share a CU to overlap it (proj at l=256: 593 us vs 542 us).
+    const double e128 = (epi != VARHIP_EPI_NONE && K <= 2048) ? 0.95 : 1.0;
+    const double c128 = cost(128, 128, 2, e128), c12864 = cost(128, 64, 3, 1.0), c64 = cost(64, 64, 4, 0.985);
     int pick = !vec ? 3 : (c128 <= c12864 && c128 <= c64) ? 0 : (c12864 <= c64 ? 1 : 2);
     static const int forced = [] { const char* e = getenv("VARHIP_GEMM_TILE"); return e ? atoi(e) : -1; }();   // experiments only
     // fewer 64x64 tiles than half the CUs (the l = 1 and l = 4 scales): the lone workgroup of a CU is bound by one LDS round trip
@@ -468,6 +475,7 @@ extern "C" int varhip_gemm_nt_f32(const float* A, int64_t lda, const float* W, i
 
 // tile choice of the implicit-GEMM convolutions: the N tile divides Cout (160/320/640 -> 160 wide); Cin % 32 == 0 so that a
 // K tile of 32 lies inside one tap
+static int conv_family(int up2, int Cout) { return (up2 != 1 && Cout % 160 == 0) ? VH_FAM_CONV : VH_FAM_CONV_SMALL; }   // as launch_conv picks
 static int launch_conv(GemmP& p, int batch, hipStream_t s) {
     if (p.up2 == 1) {                                                 // nearest-2x gather (not on the hot path)
         if (p.N % 160 == 0) return launch_dma<4, 5, true, 2, true>(p, batch, s);
@@ -527,7 +535,7 @@ static int conv3x3_impl(const float* in, const float* w, const float* bias, cons
     if (gn_part && !p.evec) return VARHIP_EINVAL;
     p.gn_part = gn_part;
     const double npix = (double)B * H * W;
-    VhScope scope(VH_FAM_CONV, (hipStream_t)stream, 2.0 * npix * Cout * 9.0 * Cin,
+    VhScope scope(conv_family(up2, Cout), (hipStream_t)stream, 2.0 * npix * Cout * 9.0 * Cin,
                   4.0 * (npix * Cin / (up2 ? 4.0 : 1.0) + npix * Cout * (resid ? 2.0 : 1.0) + 9.0 * Cin * Cout));
     hipStream_t s = (hipStream_t)stream;
     return launch_conv(p, 1, s);
@@ -555,7 +563,7 @@ extern "C" int varhip_conv3x3_s2_nhwc_f32(const float* in, const float* w, const
     p.H = H; p.Wd = W; p.Cin = Cin; p.up2 = 3; p.out_mode = 0; p.Hi = 2 * H; p.Wi = 2 * W;
     p.evec = !((Cout & 3) || ((uintptr_t)out & 15) || ((uintptr_t)bias & 15));
     const double npix = (double)B * H * W;
-    VhScope scope(VH_FAM_CONV, (hipStream_t)stream, 2.0 * npix * Cout * 9.0 * Cin, 4.0 * (npix * 4 * Cin + npix * Cout + 9.0 * Cin * Cout));
+    VhScope scope(conv_family(3, Cout), (hipStream_t)stream, 2.0 * npix * Cout * 9.0 * Cin, 4.0 * (npix * 4 * Cin + npix * Cout + 9.0 * Cin * Cout));
     hipStream_t s = (hipStream_t)stream;
     return launch_conv(p, 1, s);
 }
@@ -601,7 +609,7 @@ static int upconv_phase_impl(const float* in, const float* w_phase, const float*
     if (gn_part && !p.evec) return VARHIP_EINVAL;
     p.gn_part = gn_part;
     const double npix = (double)B * H * W;
-    VhScope scope(VH_FAM_CONV, (hipStream_t)stream, 2.0 * npix * Cout * 4.0 * Cin, 4.0 * (npix * Cin / 4.0 + npix * Cout + 16.0 * Cin * Cout));
+    VhScope scope(conv_family(2, Cout), (hipStream_t)stream, 2.0 * npix * Cout * 4.0 * Cin, 4.0 * (npix * Cin / 4.0 + npix * Cout + 16.0 * Cin * Cout));
     hipStream_t s = (hipStream_t)stream;
     return launch_conv(p, 4, s);
 }

@@ -72,12 +72,15 @@ def conv_gn_blocks(H, W, Cout, phase=False) -> int:
 
 
 # ---- timing table --------------------------------------------------------------------------------------------------
+NFAM = 10            # VARHIP_NFAM of include/var_hip.h
+
+
 def timing_enable(on: bool, families=None):
     """families: names of the kernel families to time (None = all); each timed launch records two events on the stream"""
     so = lib().so
     mask = -1
     if families is not None:
-        names = [so.varhip_timing_name(i).decode() for i in range(9)]
+        names = [so.varhip_timing_name(i).decode() for i in range(NFAM)]
         mask = sum(1 << names.index(f) for f in families)
     so.varhip_timing_select(mask)
     so.varhip_timing_enable(1 if on else 0)
@@ -89,7 +92,7 @@ def timing_reset():
 
 def timing_read():
     """-> {family: dict(ms, flops, bytes, launches)} (synchronises the recorded events)"""
-    n = abi_nfam = 9
+    n = abi_nfam = NFAM
     ms = (ctypes.c_double * n)(); fl = (ctypes.c_double * n)(); by = (ctypes.c_double * n)(); ln = (ctypes.c_int64 * n)()
     lib().so.varhip_timing_read(ms, fl, by, ln)
     return {lib().so.varhip_timing_name(i).decode(): dict(ms=ms[i], flops=fl[i], bytes=by[i], launches=int(ln[i])) for i in range(abi_nfam)}
