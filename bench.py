@@ -47,7 +47,7 @@ def main():
     from var_amd.multi import sample_sharded
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world > 1:
+    if world > 1 or ('RANK' in os.environ and 'MASTER_ADDR' in os.environ):      # under torchrun, a 1-rank launch too (exercises RCCL)
         dist.initialize(backend='nccl')
     else:
         torch.cuda.set_device(0)
@@ -130,8 +130,7 @@ def main():
             out['cpu_baseline'] = cpu_baseline(args.depth, pns)
         print(json.dumps(out), flush=True)
     dist.barrier()
-    if world > 1:
-        dist.finalize()
+    dist.finalize()
 
 
 def cpu_baseline(depth, pns):

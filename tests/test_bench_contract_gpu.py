@@ -35,3 +35,39 @@ def test_bench_line_has_the_contract_keys():
     assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and r['peak'] == 157.3 and 0 < r['frac'] < 1
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
     assert 'cpu_baseline' not in j
+
+
+_RCCL_CHILD = r'''
+import os, sys, torch
+sys.path.insert(0, os.environ["VAR_AMD_ROOT"])
+from var_amd import dist
+dist.initialize(backend="nccl")
+assert dist.initialized() and dist.get_world_size() == 1 and dist.get_rank() == 0
+x = torch.arange(24, dtype=torch.float32, device="cuda").view(2, 3, 4)
+y = dist.allgather(x)                                   # all_gather_into_tensor through RCCL
+assert y.shape == (2, 3, 4) and torch.equal(x, y)
+parts = dist.allgather(x, cat=False)
+assert len(parts) == 1 and torch.equal(parts[0], x)
+t = torch.ones(5, device="cuda"); dist.allreduce(t); assert float(t.sum()) == 5.0
+dist.barrier(); dist.finalize(); print("rccl-ok")
+'''
+
+
+def test_rccl_process_group_on_one_rank():
+    """the collectives of the N>1 path (init, barrier, all-gather, all-reduce) through RCCL itself, as far as one GPU allows: a
+    1-rank process group (the 2-rank logic runs under gloo in tests/test_host_cpu.py)"""
+    env = dict(os.environ, RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(util.free_port()),
+               VAR_AMD_ROOT=util.ROOT, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, '-c', _RCCL_CHILD], cwd=util.ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and 'rccl-ok' in out.stdout, out.stderr[-2000:]
+
+
+def test_bench_under_a_one_rank_torchrun_launch():
+    """the driver's N>1 command line with one rank: bench.py joins the RCCL group, times between barriers and still prints one line"""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', str(util.free_port()), os.path.join(util.ROOT, 'bench.py'), '--gpus', '1', '--batch', '2', '--steps', '1',
+           '--warmup', '0', '--no-cpu-baseline']
+    out = subprocess.run(cmd, cwd=util.ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1 and json.loads(lines[0])['n_gpus'] == 1

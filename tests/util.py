@@ -84,3 +84,11 @@ def diff_report(name, got, want, atol=0.0, rtol=0.0):
     if nbad:
         i = tuple(np.argwhere(bad)[0]); msg += f', first at {i}: got {got[i]!r} want {want[i]!r}'
     return nbad == 0, msg
+
+
+def free_port() -> int:
+    """a TCP port nobody listens on right now (rendezvous of child process groups on 127.0.0.1)"""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]

@@ -49,7 +49,9 @@ def set_gpu_id(gpu_id):
 
 
 def barrier():
-    if _state['init']: tdist.barrier()
+    if not _state['init']: return
+    if tdist.get_backend() == 'nccl': tdist.barrier(device_ids=[_state['local_rank']])      # name the device: no guessing, no warning
+    else: tdist.barrier()
 
 
 def allreduce(t: torch.Tensor, async_op=False):
