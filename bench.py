@@ -73,8 +73,8 @@ def main():
         step(i)
     # HIP events around the launches, on the launch stream: every family with --kernel-breakdown, else only the dominant kernel.
     # profiles/r01_bench_kernel_stats.csv: at d16 the decoder's 128x160 implicit-GEMM conv instantiation leads (33 % of the device
-    # time; the transformer GEMMs are spread over four tile instantiations of the same kernel, the largest at 21 %); from d20 up
-    # the 128x128 transformer GEMM instantiation leads.
+    # time; the transformer GEMMs are spread over four tile instantiations of the same kernel, the largest at 21 %); at d30 (measured: 28 %)
+    # the 128x128 transformer GEMM instantiation leads; depths in between are assumed to follow d30.
     dominant = 'conv3x3' if args.depth <= 16 else 'gemm'
     hip.timing_reset(); hip.timing_enable(True, None if args.kernel_breakdown else [dominant])
     dist.barrier(); torch.cuda.synchronize()
