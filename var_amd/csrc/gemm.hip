@@ -79,6 +79,14 @@ template <int MAXA, int PER> __device__ __forceinline__ void vh_wait_dma_and_bar
     else { if (ahead >= MAXA) vh_waitcnt_barrier<MAXA * PER>(); else vh_wait_dma_and_barrier<MAXA - 1, PER>(ahead); }
 }
 
+// One LDS-DMA request in the "scalar base + 32-bit vector offset" form: 16 bytes per lane from base + voff to LDS address `lds`
+// (+ 16 * lane).  Written as inline assembly because the compiler hoists the zero-extension of the offset out of the K loop and
+// then only sees a 64-bit vector address (v_lshl_add_u64 per request).  The waitcnt pass does not see these requests: every
+// barrier that publishes a tile spells out its own s_waitcnt vmcnt (vh_waitcnt_barrier).
+__device__ __forceinline__ void vh_dma16(const void* base, uint32_t voff, uint32_t lds) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(base), "s"(lds) : "memory");
+}
+
 // GATHER: the nearest-2x gather mode of the convolution (up2 == 1; tests and the oracle comparison only — the decoder runs the
 // phase form), kept out of the common kernels so that their tap address stays two adds and a select
 template <int TMW, int TNW, bool CONV, int NST = 2, bool GATHER = false>
@@ -109,7 +117,10 @@ __global__ void __launch_bounds__(256) k_dma_gemm(GemmP p) {
     // DMA roles: wave w stages rows [w*BM/4, (w+1)*BM/4) of the activation tile and [w*BN/4, ...) of the weight tile.
     // Rows past M / N are clamped to the last valid row: they only feed outputs that are never stored.
     const int drow = lane >> 3, dslot = lane & 7;
-    const float* asrc[NIA]; const float* bsrc[NIB];
+    // GEMM-mode activations and all weights are addressed as "uniform base (SGPRs) + per-lane 32-bit byte offset": the offsets are
+    // loop constants and advancing K is scalar arithmetic, so a DMA request costs no vector-ALU instruction (the 64-bit per-lane
+    // address adds it replaces sat in the MFMA stream: ~20 of them per K tile).  The host checks that the offsets fit 32 bits.
+    const float* asrc[NIA]; uint32_t aoff[NIA], boff[NIB];
     // CONV: a_y/a_x = the row's pixel in source coordinates before the tap offset (2y, 2x for the stride-2 mode); asrc = address of
     // that pixel's channel 0 (+ swizzle), so a tap is one scalar offset away: ((dy*Wi + dx)*Cin + ci0).  Only the nearest-2x
     // gather mode (up2 == 1), whose source index is not linear in the tap, recomputes the full address (a_b kept for it).
@@ -124,14 +135,14 @@ __global__ void __launch_bounds__(256) k_dma_gemm(GemmP p) {
             asrc[i] = Ab + ((dslot ^ drow) << 2);
             if (!GATHER) asrc[i] += (((int64_t)a_b[i] * p.Hi + a_y[i]) * p.Wi + a_x[i]) * p.Cin;
         } else {
-            asrc[i] = Ab + (int64_t)m * p.lda + ((dslot ^ drow) << 2);
+            aoff[i] = (uint32_t)(((int64_t)m * p.lda + ((dslot ^ drow) << 2)) * 4);
         }
     }
     const float* zsrc = g_zero_row + ((dslot ^ drow) << 2);
 #pragma unroll
     for (int i = 0; i < NIB; ++i) {
         int n = n0 + wave * (BN / 4) + i * 8 + drow; n = n < p.N ? n : p.N - 1;
-        bsrc[i] = Wb + (int64_t)n * p.ldw + ((dslot ^ drow) << 2);
+        boff[i] = (uint32_t)(((int64_t)n * p.ldw + ((dslot ^ drow) << 2)) * 4);
     }
     int cv_tap = 0, cv_cc = 0;                                    // CONV: tap / channel chunk of the next K tile to be requested
     const int cv_ntap = CONV ? p.K / p.Cin : 1, cv_hlim = CONV ? (p.up2 == 3 ? p.Hi : p.H) : 0, cv_wlim = CONV ? (p.up2 == 3 ? p.Wi : p.Wd) : 0;
@@ -164,16 +175,16 @@ __global__ void __launch_bounds__(256) k_dma_gemm(GemmP p) {
                 const bool ok = (unsigned)yy < (unsigned)cv_hlim && (unsigned)xx < (unsigned)cv_wlim;
                 if (GATHER) src = ok ? asrc[i] + (((int64_t)a_b[i] * p.Hi + (yy >> 1)) * p.Wi + (xx >> 1)) * p.Cin + ci0 : zsrc;
                 else src = ok ? asrc[i] + toff : zsrc;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(sA + i * 8 * BK), 16, 0, 0);
             } else {
-                src = asrc[i] + kt * BK;
+                vh_dma16((const char*)Ab + (size_t)kt * (BK * 4), aoff[i],
+                         (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(sA + i * 8 * BK));
             }
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(sA + i * 8 * BK), 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < NIB; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[i] + woff),
-                                             (__attribute__((address_space(3))) void*)(sB + i * 8 * BK), 16, 0, 0);
+            vh_dma16((const char*)Wb + (size_t)woff * 4, boff[i], (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(sB + i * 8 * BK));
     };
 
     f32x4 acc[TMW][TNW];
@@ -232,20 +243,20 @@ __global__ void __launch_bounds__(256) k_dma_gemm(GemmP p) {
     };
     if constexpr (NST == 2) {
         dma_tile(0, 0);
-        __syncthreads();                                          // includes the wait for this wave's own DMA (vmcnt)
+        vh_waitcnt_barrier<0>();                                  // wait for this wave's own DMA (vmcnt), then publish
         if (idle_wave) {                                          // same requests and barriers, no matrix work (kept out of the hot loop)
-            for (int kt = 0; kt < nk; ++kt) { if (kt + 1 < nk) dma_tile(kt + 1, (kt & 1) ^ 1); __syncthreads(); }
+            for (int kt = 0; kt < nk; ++kt) { if (kt + 1 < nk) dma_tile(kt + 1, (kt & 1) ^ 1); vh_waitcnt_barrier<0>(); }
         } else {
             // two K tiles per trip, so the LDS stage is a compile-time constant in each copy of the tile body: the operand reads
             // then take their stage/tile offsets as instruction immediates instead of one v_add per read
             int kt = 0;
             for (; kt + 1 < nk; kt += 2) {
                 compute(0, [&] { dma_tile(kt + 1, 1); });                  // stage 1 was last read before the previous barrier
-                __syncthreads();
+                vh_waitcnt_barrier<0>();
                 compute(1, [&] { if (kt + 2 < nk) dma_tile(kt + 2, 0); });
-                __syncthreads();
+                vh_waitcnt_barrier<0>();
             }
-            if (kt < nk) { compute(0, [] {}); __syncthreads(); }           // odd tile count: the last tile sits in stage 0
+            if (kt < nk) { compute(0, [] {}); vh_waitcnt_barrier<0>(); }   // odd tile count: the last tile sits in stage 0
         }
     } else {
         // Deep pipeline for launches with fewer workgroups than CUs (small scales): NST-1 tiles in flight, so the K loop of the
@@ -430,7 +441,9 @@ extern "C" int varhip_gemm_nt_f32(const float* A, int64_t lda, const float* W, i
                                   const float* resid, int64_t ldr, const float* gamma, int64_t ldg, int rows_per_group,
                                   int bias_per_row, int batch, int64_t sA, int64_t sW, int64_t sO, varhip_stream_t stream) {
     if (M < 0 || N <= 0 || K <= 0 || batch < 1) return VARHIP_EINVAL;
-    const bool vec = !((K & 31) || (lda & 3) || (ldw & 3) || (sA & 3) || (sW & 3) || (((uintptr_t)A | (uintptr_t)W) & 15));
+    // the DMA kernel addresses a lane's row as a 32-bit byte offset from the (per-batch) operand base
+    const bool fits32 = ((int64_t)(M > 0 ? M - 1 : 0) * lda + K) * 4 < (1ll << 32) && ((int64_t)(N - 1) * ldw + K) * 4 < (1ll << 32);
+    const bool vec = fits32 && !((K & 31) || (lda & 3) || (ldw & 3) || (sA & 3) || (sW & 3) || (((uintptr_t)A | (uintptr_t)W) & 15));
     if (batch > 1 && (resid || gamma)) return VARHIP_EINVAL;
     if (epi < 0 || epi > 2 || (epi == VARHIP_EPI_RESID && !resid)) return VARHIP_EINVAL;
     if (M == 0) return 0;
@@ -477,6 +490,7 @@ extern "C" int varhip_gemm_nt_f32(const float* A, int64_t lda, const float* W, i
 // K tile of 32 lies inside one tap
 static int conv_family(int up2, int Cout) { return (up2 != 1 && Cout % 160 == 0) ? VH_FAM_CONV : VH_FAM_CONV_SMALL; }   // as launch_conv picks
 static int launch_conv(GemmP& p, int batch, hipStream_t s) {
+    if ((int64_t)p.N * p.ldw * 4 >= (1ll << 32)) return VARHIP_EINVAL;      // weight rows are 32-bit DMA offsets from the (per-phase) base
     if (p.up2 == 1) {                                                 // nearest-2x gather (not on the hot path)
         if (p.N % 160 == 0) return launch_dma<4, 5, true, 2, true>(p, batch, s);
         if (p.N % 64 == 0) return launch_dma<4, 2, true, 2, true>(p, batch, s);
@@ -496,6 +510,7 @@ extern "C" int varhip_gemm_qkv_f32(const float* A, int64_t lda, const float* W, 
                                    varhip_stream_t stream) {
     if (B2 <= 0 || l <= 0 || H <= 0 || pos0 < 0 || pos0 + l > Lmax || (l2norm && !scale_mul)) return VARHIP_EINVAL;
     if (C != H * 64 || M != B2 * l || K <= 0 || (K & 31) || (lda & 3) || (ldw & 3)) return VARHIP_EINVAL;
+    if (((int64_t)(M - 1) * lda + K) * 4 >= (1ll << 32) || ((int64_t)(3 * C - 1) * ldw + K) * 4 >= (1ll << 32)) return VARHIP_EINVAL;   // 32-bit DMA offsets
     if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)bias | (uintptr_t)q_out | (uintptr_t)kcache | (uintptr_t)vcache) & 15)) return VARHIP_EINVAL;
     GemmP p{};
     p.A = A; p.W = W; p.bias = bias; p.lda = lda; p.ldw = ldw;
