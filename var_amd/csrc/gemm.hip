@@ -87,6 +87,13 @@ __device__ __forceinline__ void vh_dma16(const void* base, uint32_t voff, uint32
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(base), "s"(lds) : "memory");
 }
 
+// The same through a buffer descriptor: 16 bytes per lane from rsrc.base + soff + voff.  A request whose voff lies at or beyond
+// rsrc.num_records is out of range for the hardware bounds check and delivers zeros to its LDS slot — the zero padding of the
+// convolution costs one OR into the offset instead of a 64-bit address select.
+__device__ __forceinline__ void vh_dma16_buf(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff, uint32_t lds) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds) : "memory");
+}
+
 // GATHER: the nearest-2x gather mode of the convolution (up2 == 1; tests and the oracle comparison only — the decoder runs the
 // phase form), kept out of the common kernels so that their tap address stays two adds and a select
 template <int TMW, int TNW, bool CONV, int NST = 2, bool GATHER = false>
@@ -125,6 +132,23 @@ __global__ void __launch_bounds__(256) k_dma_gemm(GemmP p) {
     // that pixel's channel 0 (+ swizzle), so a tap is one scalar offset away: ((dy*Wi + dx)*Cin + ci0).  Only the nearest-2x
     // gather mode (up2 == 1), whose source index is not linear in the tap, recomputes the full address (a_b kept for it).
     int a_b[NIA], a_y[NIA], a_x[NIA];
+    // CONV without the gather: the input is read through a buffer descriptor whose window starts one row + one pixel before the
+    // first sample the tile touches (so every tap offset is a non-negative scalar) and is < 2 GB long (host-checked); aoff = the
+    // pixel's byte offset in that window, abad bit t = tap t of this pixel is zero padding.  A padded tap ORs bit 31 into the
+    // offset, which puts the request out of range of the window: the bounds check writes zeros to the LDS slot.
+    uint32_t abad[NIA];
+    const float* rs_base = Ab; int64_t rs_bytes = 0;
+    const int cv_pre = (CONV && p.up2 != 3) ? 1 : 0;              // taps reach one row / column back (not in the stride-2 mode)
+    const int cv_ntap = CONV ? p.K / p.Cin : 1, cv_hlim = CONV ? (p.up2 == 3 ? p.Hi : p.H) : 0, cv_wlim = CONV ? (p.up2 == 3 ? p.Wi : p.Wd) : 0;
+    int cv_b0 = 0;
+    if constexpr (CONV && !GATHER) {
+        const int hw = p.H * p.Wd, mlast = (m0 + BM - 1 < p.M ? m0 + BM - 1 : p.M - 1), mfirst = m0 < p.M ? m0 : p.M - 1;
+        cv_b0 = mfirst / hw;
+        const int64_t sample = (int64_t)p.Hi * p.Wi * p.Cin, shift = (int64_t)cv_pre * (p.Wi + 1) * p.Cin;
+        rs_bytes = ((int64_t)(mlast / hw - cv_b0 + 1) * sample + shift) * 4;
+        rs_base = Ab + (int64_t)cv_b0 * sample - shift;
+    }
+    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)rs_base, 0, (int)rs_bytes, 0x00020000);
 #pragma unroll
     for (int i = 0; i < NIA; ++i) {
         int m = m0 + wave * (BM / 4) + i * 8 + drow; m = m < p.M ? m : p.M - 1;
@@ -133,7 +157,18 @@ __global__ void __launch_bounds__(256) k_dma_gemm(GemmP p) {
             a_b[i] = m / hw; const int rem2 = m - a_b[i] * hw; a_y[i] = rem2 / p.Wd; a_x[i] = rem2 - a_y[i] * p.Wd;
             if (p.up2 == 3) { a_y[i] *= 2; a_x[i] *= 2; }
             asrc[i] = Ab + ((dslot ^ drow) << 2);
-            if (!GATHER) asrc[i] += (((int64_t)a_b[i] * p.Hi + a_y[i]) * p.Wi + a_x[i]) * p.Cin;
+            if constexpr (!GATHER) {
+                aoff[i] = (uint32_t)(((((int64_t)(a_b[i] - cv_b0) * p.Hi + a_y[i]) * p.Wi + a_x[i]) * p.Cin + ((dslot ^ drow) << 2)) * 4);
+                uint32_t bad = 0;
+                for (int t = 0; t < cv_ntap; ++t) {
+                    int dy, dx;
+                    if (p.up2 == 2) { dy = (t >> 1) - 1 + (bz >> 1); dx = (t & 1) - 1 + (bz & 1); }
+                    else { const int ky = t / 3; dy = ky - cv_pre; dx = t - ky * 3 - cv_pre; }
+                    const bool ok = (unsigned)(a_y[i] + dy) < (unsigned)cv_hlim && (unsigned)(a_x[i] + dx) < (unsigned)cv_wlim;
+                    bad |= ok ? 0u : (1u << t);
+                }
+                abad[i] = bad;
+            }
         } else {
             aoff[i] = (uint32_t)(((int64_t)m * p.lda + ((dslot ^ drow) << 2)) * 4);
         }
@@ -145,12 +180,11 @@ __global__ void __launch_bounds__(256) k_dma_gemm(GemmP p) {
         boff[i] = (uint32_t)(((int64_t)n * p.ldw + ((dslot ^ drow) << 2)) * 4);
     }
     int cv_tap = 0, cv_cc = 0;                                    // CONV: tap / channel chunk of the next K tile to be requested
-    const int cv_ntap = CONV ? p.K / p.Cin : 1, cv_hlim = CONV ? (p.up2 == 3 ? p.Hi : p.H) : 0, cv_wlim = CONV ? (p.up2 == 3 ? p.Wi : p.Wd) : 0;
     auto dma_tile = [&](int kt, int st) {                         // K tiles must be requested in order 0, 1, 2, ...
         float* sA = smem + st * STAGE + wave * (BM / 4) * BK;
         float* sB = smem + st * STAGE + BM * BK + wave * (BN / 4) * BK;
-        int dy = 0, dx = 0, ci0 = 0, woff = kt * BK;
-        int64_t toff = 0;
+        int dy = 0, dx = 0, ci0 = 0, woff = kt * BK, tap = 0;
+        uint32_t soff = 0;
         if (CONV) {
             // Summation order of the convolutions: 32-channel chunks outermost, then the taps, then the channels of the chunk
             // (K tile kt = chunk kt / ntap, tap kt % ntap; the tiles are requested in order, so two counters replace the division).
@@ -158,25 +192,26 @@ __global__ void __launch_bounds__(256) k_dma_gemm(GemmP p) {
             // inside the XCD's L2: tap-major order moved 6.7 GB per 256x256 launch across the fabric, this order 2.4 GB
             // (algorithmic 1.6 GB; profiles/r01_pmc_traffic.json).  Weights keep the [Cout][tap][Cin] layout: the tile's weights
             // are the 32 floats at tap*Cin + ci0 of every row.
-            const int tap = cv_tap;
+            tap = cv_tap;
             ci0 = cv_cc * BK;
             woff = tap * p.Cin + ci0;
             if (++cv_tap == cv_ntap) { cv_tap = 0; ++cv_cc; }
             if (p.up2 == 2) { dy = (tap >> 1) - 1 + (bz >> 1); dx = (tap & 1) - 1 + (bz & 1); }   // phase (bz>>1, bz&1) of the folded Upsample2x conv
             else { const int ky = tap / 3; dy = ky - (p.up2 == 3 ? 0 : 1); dx = tap - ky * 3 - (p.up2 == 3 ? 0 : 1); }
-            toff = ((int64_t)dy * p.Wi + dx) * p.Cin + ci0;
+            soff = (uint32_t)(((dy + cv_pre) * p.Wi + dx + cv_pre) * p.Cin + ci0) * 4u;      // tap offset inside the descriptor window
         }
 #pragma unroll
         for (int i = 0; i < NIA; ++i) {
-            const float* src;
-            if (CONV) {
-                // up2: 0 plain, 1 nearest-2x gather, 2 phase conv on the low-res map, 3 stride 2 over an input zero-padded at the bottom/right
+            // up2: 0 plain, 1 nearest-2x gather, 2 phase conv on the low-res map, 3 stride 2 over an input zero-padded at the bottom/right
+            if constexpr (CONV && GATHER) {
                 const int yy = a_y[i] + dy, xx = a_x[i] + dx;
                 const bool ok = (unsigned)yy < (unsigned)cv_hlim && (unsigned)xx < (unsigned)cv_wlim;
-                if (GATHER) src = ok ? asrc[i] + (((int64_t)a_b[i] * p.Hi + (yy >> 1)) * p.Wi + (xx >> 1)) * p.Cin + ci0 : zsrc;
-                else src = ok ? asrc[i] + toff : zsrc;
+                const float* src = ok ? asrc[i] + (((int64_t)a_b[i] * p.Hi + (yy >> 1)) * p.Wi + (xx >> 1)) * p.Cin + ci0 : zsrc;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(sA + i * 8 * BK), 16, 0, 0);
+            } else if constexpr (CONV) {
+                vh_dma16_buf(arsrc, ((abad[i] >> tap) << 31) | aoff[i], soff,
+                             (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(sA + i * 8 * BK));
             } else {
                 vh_dma16((const char*)Ab + (size_t)kt * (BK * 4), aoff[i],
                          (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(sA + i * 8 * BK));
@@ -491,6 +526,10 @@ extern "C" int varhip_gemm_nt_f32(const float* A, int64_t lda, const float* W, i
 static int conv_family(int up2, int Cout) { return (up2 != 1 && Cout % 160 == 0) ? VH_FAM_CONV : VH_FAM_CONV_SMALL; }   // as launch_conv picks
 static int launch_conv(GemmP& p, int batch, hipStream_t s) {
     if ((int64_t)p.N * p.ldw * 4 >= (1ll << 32)) return VARHIP_EINVAL;      // weight rows are 32-bit DMA offsets from the (per-phase) base
+    {   // the input window of one workgroup's buffer descriptor (the samples a 128-pixel tile can touch + one row) must stay < 2 GB
+        const int64_t hw = (int64_t)p.H * p.Wd, sample = (int64_t)p.Hi * p.Wi * p.Cin;
+        if (p.up2 != 1 && ((127 / hw + 2) * sample + (int64_t)(p.Wi + 1) * p.Cin) * 4 >= (1ll << 31)) return VARHIP_EINVAL;
+    }
     if (p.up2 == 1) {                                                 // nearest-2x gather (not on the hot path)
         if (p.N % 160 == 0) return launch_dma<4, 5, true, 2, true>(p, batch, s);
         if (p.N % 64 == 0) return launch_dma<4, 2, true, 2, true>(p, batch, s);
