@@ -71,7 +71,7 @@ __global__ void __launch_bounds__(256) k_gemm_any(GemmP p) {
 // a lane ends up with 4 consecutive n of one m and the epilogue (bias / GELU / gamma / residual / q-k-v prep) runs on float4s
 // straight from the accumulators, no LDS transpose.
 // 2x2 waves; a wave owns (TMW*16) x (TNW*16) outputs.  Two LDS stages, one barrier per K tile.
-__device__ __attribute__((aligned(128))) float g_zero_row[32];      // source of the zero padding taps of the convolution (never written)
+__device__ __attribute__((aligned(128))) float g_zero_row[32];      // zero padding source of the nearest-2x GATHER mode only (never written)
 
 template <int N> __device__ __forceinline__ void vh_waitcnt_barrier() { asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory"); }
 template <int MAXA, int PER> __device__ __forceinline__ void vh_wait_dma_and_barrier(int ahead) {      // `ahead` is wave-uniform
