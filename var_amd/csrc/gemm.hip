@@ -91,7 +91,9 @@ __device__ __forceinline__ void vh_dma16(const void* base, uint32_t voff, uint32
 // rsrc.num_records is out of range for the hardware bounds check and delivers zeros to its LDS slot — the zero padding of the
 // convolution costs one OR into the offset instead of a 64-bit address select.
 __device__ __forceinline__ void vh_dma16_buf(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff, uint32_t lds) {
-    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds) : "memory");
+    // (readfirstlane: a value the compiler computed on the vector ALU although it is wave-uniform must still reach an SGPR operand)
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                 : : "v"(voff), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane(soff)), "s"(__builtin_amdgcn_readfirstlane(lds)) : "memory");
 }
 
 // GATHER: the nearest-2x gather mode of the convolution (up2 == 1; tests and the oracle comparison only — the decoder runs the
@@ -149,28 +151,40 @@ __global__ void __launch_bounds__(256) k_dma_gemm(GemmP p) {
         rs_base = Ab + (int64_t)cv_b0 * sample - shift;
     }
     const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)rs_base, 0, (int)rs_bytes, 0x00020000);
+    // pixel coordinates of the lane's NIA rows (8 apart): one division pair for the first, the others by stepping — the prologue's
+    // integer divisions and tap tests are paid by every workgroup while its SIMDs' matrix pipes wait
+    const bool cv_step = CONV && p.Wd >= 8 && m0 + BM <= p.M;
 #pragma unroll
     for (int i = 0; i < NIA; ++i) {
         int m = m0 + wave * (BM / 4) + i * 8 + drow; m = m < p.M ? m : p.M - 1;
         if (CONV) {
             const int hw = p.H * p.Wd;
-            a_b[i] = m / hw; const int rem2 = m - a_b[i] * hw; a_y[i] = rem2 / p.Wd; a_x[i] = rem2 - a_y[i] * p.Wd;
+            if (i == 0 || !cv_step) {
+                a_b[i] = m / hw; const int rem2 = m - a_b[i] * hw; a_y[i] = rem2 / p.Wd; a_x[i] = rem2 - a_y[i] * p.Wd;
+            } else {
+                a_b[i] = a_b[i - 1]; a_y[i] = a_y[i - 1]; a_x[i] = a_x[i - 1] + 8;
+                if (a_x[i] >= p.Wd) { a_x[i] -= p.Wd; if (++a_y[i] == p.H) { a_y[i] = 0; ++a_b[i]; } }
+            }
+        } else {
+            aoff[i] = (uint32_t)(((int64_t)m * p.lda + ((dslot ^ drow) << 2)) * 4);
+        }
+    }
+    if constexpr (CONV) {
+#pragma unroll
+        for (int i = 0; i < NIA; ++i) {
             if (p.up2 == 3) { a_y[i] *= 2; a_x[i] *= 2; }
             asrc[i] = Ab + ((dslot ^ drow) << 2);
             if constexpr (!GATHER) {
                 aoff[i] = (uint32_t)(((((int64_t)(a_b[i] - cv_b0) * p.Hi + a_y[i]) * p.Wi + a_x[i]) * p.Cin + ((dslot ^ drow) << 2)) * 4);
-                uint32_t bad = 0;
-                for (int t = 0; t < cv_ntap; ++t) {
-                    int dy, dx;
-                    if (p.up2 == 2) { dy = (t >> 1) - 1 + (bz >> 1); dx = (t & 1) - 1 + (bz & 1); }
-                    else { const int ky = t / 3; dy = ky - cv_pre; dx = t - ky * 3 - cv_pre; }
-                    const bool ok = (unsigned)(a_y[i] + dy) < (unsigned)cv_hlim && (unsigned)(a_x[i] + dx) < (unsigned)cv_wlim;
-                    bad |= ok ? 0u : (1u << t);
-                }
-                abad[i] = bad;
+                // tap t = 3*ky + kx (2*a + b in the phase mode) pads iff its row offset or its column offset leaves the image
+                const int dy0 = p.up2 == 2 ? (bz >> 1) - 1 : -cv_pre, dx0 = p.up2 == 2 ? (bz & 1) - 1 : -cv_pre;
+                const bool r0 = (unsigned)(a_y[i] + dy0) >= (unsigned)cv_hlim, r1 = (unsigned)(a_y[i] + dy0 + 1) >= (unsigned)cv_hlim,
+                           r2 = (unsigned)(a_y[i] + dy0 + 2) >= (unsigned)cv_hlim;
+                const bool c0 = (unsigned)(a_x[i] + dx0) >= (unsigned)cv_wlim, c1 = (unsigned)(a_x[i] + dx0 + 1) >= (unsigned)cv_wlim,
+                           c2 = (unsigned)(a_x[i] + dx0 + 2) >= (unsigned)cv_wlim;
+                abad[i] = p.up2 == 2 ? ((r0 ? 0x3u : 0u) | (r1 ? 0xCu : 0u) | (c0 ? 0x5u : 0u) | (c1 ? 0xAu : 0u))
+                                     : ((r0 ? 0x007u : 0u) | (r1 ? 0x038u : 0u) | (r2 ? 0x1C0u : 0u) | (c0 ? 0x049u : 0u) | (c1 ? 0x092u : 0u) | (c2 ? 0x124u : 0u));
             }
-        } else {
-            aoff[i] = (uint32_t)(((int64_t)m * p.lda + ((dslot ^ drow) << 2)) * 4);
         }
     }
     const float* zsrc = g_zero_row + ((dslot ^ drow) << 2);
