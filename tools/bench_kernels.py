@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Micro-benchmarks of the hot kernels at the shapes the d16 / B=64 sampling call launches (run on the GPU box).
 
-  python tools/bench_kernels.py gemm|conv|attn|all [--iters N]
+  python tools/bench_kernels.py gemm|qkv|conv|attn|all [--iters N]
 Times each shape with torch CUDA events on the launch stream, interleaving shapes over rounds (cdna guide rule 24), and
 prints TFLOP/s against the fp32 MFMA peak.  Used to A/B kernel variants; numbers quoted in DESIGN.md come from bench.py."""
 import argparse
@@ -57,6 +57,27 @@ def run_gemm(iters, rounds=3):
         print(f'gemm {name:14s} M={M:6d} N={N:5d} K={K:5d} epi={epi}: {ms*1e3:9.1f} us  {tf:7.1f} TF  {tf/PEAK*100:5.1f}%', flush=True)
 
 
+def run_qkv(iters, rounds=3):
+    """mat_qkv with the fused q/k/v epilogue (varhip_gemm_qkv_f32) at the d16 / B=64 shapes"""
+    dev, B2, H, C, K, Lmax = 'cuda', 128, 16, 1024, 1024, 680
+    W = torch.randn(3 * C, K, device=dev) * 0.03; bias = torch.randn(3 * C, device=dev); smul = torch.full((H,), 1.386, device=dev)
+    kc = torch.empty(B2, H, Lmax, 64, device=dev); vc = torch.empty_like(kc)
+    res, pos = {}, 0
+    for r in range(rounds):
+        pos = 0
+        for pn in (1, 2, 3, 4, 5, 6, 8, 10, 13, 16):
+            l = pn * pn; M = B2 * l
+            A = torch.randn(M, K, device=dev); q = torch.empty(M, C, device=dev); p0 = pos
+            fn = lambda: hip.call('gemm_qkv_f32', A, K, W, K, bias, M, C, K, smul, 1.0, 1, q, kc, vc, B2, l, H, p0, Lmax)
+            res.setdefault(l, []).append(timeit(fn, iters if l >= 36 else iters * 4))
+            pos += l
+    tot = 0.0
+    for l, v in res.items():
+        ms = min(v); tf = 2.0 * B2 * l * 3 * C * K / ms / 1e9; tot += ms
+        print(f'qkvfused l={l:3d}: {ms*1e3:9.1f} us  {tf:7.1f} TF  {tf/PEAK*100:5.1f}%', flush=True)
+    print(f'qkvfused total {tot*1e3:.1f} us per layer', flush=True)
+
+
 def run_conv(iters):
     dev = 'cuda'
     for (B, H, W, Cin, Cout, up2, res) in [(64, 256, 256, 160, 160, 0, 1), (64, 256, 256, 160, 160, 1, 0), (64, 128, 128, 320, 160, 0, 0), (64, 128, 128, 160, 160, 0, 1),
@@ -93,5 +114,6 @@ if __name__ == '__main__':
     torch.cuda.set_device(0)
     print(hip.lib().version())
     if a.what in ('gemm', 'all'): run_gemm(a.iters)
+    if a.what in ('qkv', 'all'): run_qkv(a.iters)
     if a.what in ('conv', 'all'): run_conv(a.iters)
     if a.what in ('attn', 'all'): run_attn(a.iters)

@@ -574,7 +574,8 @@ extern "C" int varhip_gemm_qkv_f32(const float* A, int64_t lda, const float* W, 
         const int64_t nb = (int64_t)((M + bm - 1) / bm) * ((3 * C + 127) / 128);
         return (double)((nb + 255) / 256) * bm / eff;
     };
-    const bool big = cost(128, 1.0) <= cost(64, 0.97);
+    static const int forced = [] { const char* e = getenv("VARHIP_QKV_TILE"); return e ? atoi(e) : -1; }();   // experiments only: 0 = 128 rows, 1 = 64
+    const bool big = forced >= 0 ? forced == 0 : cost(128, 0.97) <= cost(64, 1.0);      // measured with the fused epilogue: the 64-row tile (3 workgroups per CU) is level or ahead at every d16 scale
     VhScope scope(big ? VH_FAM_GEMM : VH_FAM_GEMM_SMALL, (hipStream_t)stream, 2.0 * M * 3.0 * C * (double)K,
                   4.0 * ((double)M * K + 3.0 * C * K + 3.0 * M * C));
     return big ? launch_dma<4, 4>(p, 1, (hipStream_t)stream) : launch_dma<2, 4>(p, 1, (hipStream_t)stream);
