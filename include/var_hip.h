@@ -42,7 +42,8 @@ const char* varhip_version(void);
  *                           gamma == NULL means no scaling: resid + (acc + bias)       (basic_vae.py:60,92)
  *   bias may be NULL.  bias_per_row != 0: bias is indexed by m instead of n.
  *   batch >= 1 with element strides sA/sW/sO (sW or sA may be 0 to share an operand); resid/gamma only with batch==1.
- * Fast path: K % 32 == 0, lda/ldw/sA/sW % 4 == 0 and 16-byte aligned A/W; anything else takes an element-wise-load variant. */
+ * Fast path: K % 32 == 0, lda/ldw/sA/sW % 4 == 0, 16-byte aligned A/W and each operand of one batch element spanning < 4 GiB
+ * (rows are addressed as 32-bit byte offsets from a scalar base); anything else takes an element-wise-load variant. */
 #define VARHIP_EPI_NONE 0
 #define VARHIP_EPI_GELU 1
 #define VARHIP_EPI_RESID 2
@@ -76,7 +77,8 @@ int varhip_qkv_prep_f32(const float* qkv, const float* scale_mul, float plain_sc
 /* ---- mat_qkv GEMM with that post-processing fused into its epilogue -------------------------------------
  * Equivalent, bit for bit, to varhip_gemm_nt_f32(A, W[3C][K], bias[3C]) -> qkv[M][3C] followed by varhip_qkv_prep_f32,
  * without the [M][3C] round trip through HBM.   replaces basic_var.py:93 (F.linear with the q_bias|zero_k_bias|v_bias
- * concatenation) through :109.  Requires M == B2*l, C == H*64, K % 32 == 0, lda/ldw % 4 == 0, 16-byte aligned pointers. */
+ * concatenation) through :109.  Requires M == B2*l, C == H*64, K % 32 == 0, lda/ldw % 4 == 0, 16-byte aligned pointers and
+ * A and W each spanning < 4 GiB (VARHIP_EINVAL otherwise). */
 int varhip_gemm_qkv_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, int M, int C, int K,
                         const float* scale_mul, float plain_scale, int l2norm,
                         float* q_out, float* kcache, float* vcache,
@@ -158,7 +160,9 @@ int varhip_first_map_f32(const float* class_emb, const int64_t* labels, int num_
  *             (vqvae.py:63 clamp_ and var.py:190 add_(1).mul_(0.5) fused into the last conv);
  *   out_mode 2: [B][Cout][H][W] holding clamp(v,-1,1) only (VQVAE.fhat_to_img's own contract)
  * replaces every Conv2d(k=3) of basic_vae.py (ResnetBlock :48,:51; conv_in :180; conv_out :208; Upsample2x :25)
- * and vqvae.py:49 post_quant_conv.   Constraint: Cin % 32 == 0 (a K tile of the implicit GEMM lies inside one tap).
+ * and vqvae.py:49 post_quant_conv.   Constraints: Cin % 32 == 0 (a K tile of the implicit GEMM lies inside one tap); the input
+ * samples one 128-pixel tile can touch (one sample when H*W >= 128) plus one row must span < 2 GiB and the packed weights < 4 GiB
+ * (buffer-descriptor window / 32-bit offsets of the DMA requests; VARHIP_EINVAL otherwise).  The batch itself may exceed 4 GiB.
  * Summation order (arithmetic contract of every 3x3 convolution here): one fma chain per output over 32-channel chunks
  * (outermost), then the taps (ky, kx), then the channels of the chunk. */
 int varhip_conv3x3_nhwc_f32(const float* in, const float* w, const float* bias, const float* resid, float* out,
