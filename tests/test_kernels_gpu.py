@@ -146,7 +146,13 @@ def test_gemm_rejects_bad_shapes():
         hip.call('gemm_nt_f32', a, 36, a, 36, None, a, 64, 64, 64, 0, 0, None, 0, None, 0, 1, 0, 1, 0, 0, 0)      # K == 0
     with pytest.raises(VarHipError):
         hip.call('gemm_nt_f32', a, 36, a, 36, None, a, 64, 64, 64, 32, 2, None, 0, None, 0, 1, 0, 1, 0, 0, 0)     # RESID without resid
-
+    # the DMA requests carry 32-bit offsets: operands beyond those limits are refused before anything is launched (var_hip.h)
+    x = torch.zeros(1, 8, 8, 32, device='cuda'); w = torch.zeros(32, 9 * 32, device='cuda'); b = torch.zeros(32, device='cuda')
+    with pytest.raises(VarHipError):
+        hip.call('conv3x3_nhwc_f32', x, w, b, None, x, 1, 4096, 4096, 32, 32, 0, 0)      # one sample of 2 GiB: beyond the descriptor window
+    q = torch.zeros(8, device='cuda')
+    with pytest.raises(VarHipError):                                                      # A rows spanning 4 GiB
+        hip.call('gemm_qkv_f32', a, 1 << 22, a, 64, q, 257, 64, 64, q, 1.0, 0, a, a, a, 257, 1, 1, 0, 1)
 
 @pytest.mark.parametrize('M,C,rpg', [(4, 128, 1), (37, 1024, 9), (512, 1024, 4), (10, 1920, 5), (6, 2304, 2)])
 def test_ln_modulate_exact(M, C, rpg):
