@@ -5,6 +5,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o mix_exp mix_exp.hip      Run: ./mix_exp
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -102,9 +103,38 @@ static void run(float* out, int blocks, int iters) {
     fflush(stdout);
 }
 
+// workgroup turnover: how long does a CU slot stay empty between two workgroups of a launch?  Each workgroup spins for `spin`
+// matrix instructions per wave and exits; LDS per workgroup sets the number of slots per CU.
+__global__ void __launch_bounds__(256) k_turn(float* __restrict__ out, int spin, float seed) {
+    extern __shared__ float lds[];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float a = seed * threadIdx.x, b = 1.0f + seed;
+    for (int i = 0; i < spin; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    if (acc[0] == 12345.f) { lds[threadIdx.x] = acc[1]; out[blockIdx.x] = lds[threadIdx.x ^ 1]; }
+}
+static void run_turn(float* out, int lds_kb, int spin) {
+    const int slots = 160 / lds_kb, nwg = 256 * slots * 64;
+    hipFuncSetAttribute((const void*)k_turn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_kb * 1024);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k_turn, dim3(nwg), dim3(256), lds_kb * 1024, 0, out, spin, 1e-3f);
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(k_turn, dim3(nwg), dim3(256), lds_kb * 1024, 0, out, spin, 1e-3f);
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
+    // a dependent chain of `spin` 8-pass MFMAs takes >= spin * 32 cycles (~2.4 GHz); 64 rounds of workgroups per slot
+    const double ideal_us = 64.0 * spin * 40.0 / 2400.0;       // 40 cycles per dependent 16x16x4 (measured single-wave rate)
+    printf("turnover: LDS %3d KB (%d slots/CU), spin %5d: %8.1f us for 64 rounds, %6.2f us per round, compute alone ~%6.2f us per round\n",
+           lds_kb, slots, spin, ms * 1e3, ms * 1e3 / 64, ideal_us / 64);
+    fflush(stdout);
+}
+
 int main() {
     const int blocks = 256 * 2, iters = 20000;       // 2 workgroups of 4 waves per CU = 2 waves per SIMD
     float* out; if (hipMalloc(&out, (size_t)1024 * 256 * sizeof(float)) != hipSuccess) { printf("hipMalloc failed\n"); return 1; }
+    if (getenv("MIX_TURNOVER")) {
+        for (int kb : {64, 48, 32}) for (int spin : {0, 256, 1024, 4096}) run_turn(out, kb, spin);
+        hipFree(out); return 0;
+    }
     run<0, true>(out, blocks, iters);
     run<1, true>(out, blocks, iters);
     run<2, true>(out, blocks, iters);
