@@ -373,6 +373,102 @@ __global__ void __launch_bounds__(256) k_dma_gemm(GemmP p) {
             return;
         }
     }
+    // Lean epilogue of full tiles.  Vector-ALU work here is paid at several cycles per instruction (the other workgroups of the CU are
+    // in their matrix loops), so a row gets ONE 32-bit byte offset per operand relative to the tile's first row (scalar 64-bit bases),
+    // the column tiles are instruction immediates on "scalar base + offset" loads and stores, and the AdaLN gate's row group comes
+    // from one scalar division when a tile spans at most two groups.  Same arithmetic, element for element, as the general loop below.
+    bool lean_done = false;
+    if constexpr (!CONV) {
+        if (p.evec && p.bias && !p.bias_per_row && m0 + BM <= p.M && n0 + BN <= p.N && ((p.ldo | p.ldr | p.ldg) >> 22) == 0) {   // (row offsets of a tile fit 32 bits)
+            const int col = nw0 + kq * 4;
+            const bool res = p.epi == VARHIP_EPI_RESID, gam = res && p.gamma;
+            const int rpg = p.rows_per_group, g0 = m0 / rpg;
+            uint32_t ooff[TMW], roff[TMW], goff[TMW];
+#pragma unroll
+            for (int i = 0; i < TMW; ++i) {
+                const int dm = (wm * TMW + i) * 16 + r16, m = m0 + dm;
+                ooff[i] = ((uint32_t)dm * (uint32_t)p.ldo + (uint32_t)col) * 4u;
+                roff[i] = res ? ((uint32_t)dm * (uint32_t)p.ldr + (uint32_t)col) * 4u : 0u;
+                const int dg = rpg >= BM ? (m >= (g0 + 1) * rpg ? 1 : 0) : m / rpg - g0;
+                goff[i] = gam ? ((uint32_t)dg * (uint32_t)p.ldg + (uint32_t)col) * 4u : 0u;
+            }
+            char* ob = (char*)(Ob + (int64_t)m0 * p.ldo);
+            const char* rb = res ? (const char*)(p.resid + (int64_t)m0 * p.ldr) : nullptr;
+            const char* gb = gam ? (const char*)(p.gamma + (int64_t)g0 * p.ldg) : nullptr;
+#pragma unroll
+            for (int j = 0; j < TNW; ++j) {
+                const f32x4 b4 = *(const f32x4*)(p.bias + col + j * 16);
+#pragma unroll
+                for (int i = 0; i < TMW; ++i) {
+                    f32x4 v = acc[i][j] + b4;
+                    if (p.epi == VARHIP_EPI_GELU) { v[0] = vm_gelu_tanh(v[0]); v[1] = vm_gelu_tanh(v[1]); v[2] = vm_gelu_tanh(v[2]); v[3] = vm_gelu_tanh(v[3]); }
+                    if (res) {
+                        if (gam) v = v * *(const f32x4*)(gb + (uint64_t)goff[i] + j * 64);
+                        v = *(const f32x4*)(rb + (uint64_t)roff[i] + j * 64) + v;
+                    }
+                    *(f32x4*)(ob + (uint64_t)ooff[i] + j * 64) = v;
+                }
+            }
+            return;
+        }
+    }
+    if constexpr (CONV && NST == 2) {
+        // convolutions (NHWC output, full tile): the same, plus the scattered rows of the phase mode and the GroupNorm partial sums
+        if (p.evec && p.out_mode == 0 && m0 + BM <= p.M && n0 + BN <= p.N) {
+            const int col = nw0 + kq * 4, hw = p.H * p.Wd;
+            const bool res = p.epi == VARHIP_EPI_RESID, phase = p.up2 == 2;
+            int64_t mo0 = m0;                                          // output row of the tile's first pixel
+            if (phase) { const int b = m0 / hw, rem = m0 - b * hw, y = rem / p.Wd, x = rem - y * p.Wd;
+                         mo0 = ((int64_t)b * (2 * p.H) + 2 * y + (bz >> 1)) * (2 * p.Wd) + 2 * x + (bz & 1); }
+            uint32_t ooff[TMW], roff[TMW];
+            int pb = 0, py = 0, px = 0;
+#pragma unroll
+            for (int i = 0; i < TMW; ++i) {
+                const int dm = (wm * TMW + i) * 16 + r16, m = m0 + dm;
+                int64_t dmo = dm;
+                if (phase) {
+                    if (i == 0 || p.Wd < 16) { pb = m / hw; const int rem = m - pb * hw; py = rem / p.Wd; px = rem - py * p.Wd; }
+                    else { px += 16; if (px >= p.Wd) { px -= p.Wd; if (++py == p.H) { py = 0; ++pb; } } }
+                    dmo = ((int64_t)pb * (2 * p.H) + 2 * py + (bz >> 1)) * (2 * p.Wd) + 2 * px + (bz & 1) - mo0;
+                }
+                ooff[i] = ((uint32_t)dmo * (uint32_t)p.ldo + (uint32_t)col) * 4u;
+                roff[i] = res ? ((uint32_t)dm * (uint32_t)p.ldr + (uint32_t)col) * 4u : 0u;
+            }
+            char* ob = (char*)(Ob + mo0 * p.ldo);
+            const char* rb = res ? (const char*)(p.resid + (int64_t)m0 * p.ldr) : nullptr;
+#pragma unroll
+            for (int j = 0; j < TNW; ++j) {
+                const f32x4 b4 = *(const f32x4*)(p.bias + col + j * 16);
+                double gs[4] = {0.0, 0.0, 0.0, 0.0}, gq[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int i = 0; i < TMW; ++i) {
+                    f32x4 v = acc[i][j] + b4;
+                    if (res) v = *(const f32x4*)(rb + (uint64_t)roff[i] + j * 64) + v;
+                    *(f32x4*)(ob + (uint64_t)ooff[i] + j * 64) = v;
+                    if (p.gn_part) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { const double d = (double)v[e]; gs[e] += d; gq[e] += d * d; }
+                    }
+                }
+                if (p.gn_part) {                                        // as in the general loop: butterfly over the 16 pixel lanes, park in LDS
+#pragma unroll
+                    for (int off = 8; off >= 1; off >>= 1)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { gs[e] += __shfl_xor(gs[e], off, 64); gq[e] += __shfl_xor(gq[e], off, 64); }
+                    if (r16 == 0) {
+                        double* red = reinterpret_cast<double*>(smem);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int nl = (wn * TNW + j) * 16 + kq * 4 + e;
+                            red[(wm * BN + nl) * 2] = gs[e]; red[(wm * BN + nl) * 2 + 1] = gq[e];
+                        }
+                    }
+                }
+            }
+            lean_done = true;
+        }
+    }
+    if (!lean_done) {
 #pragma unroll
     for (int j = 0; j < TNW; ++j) {
         const int n = nw0 + j * 16 + kq * 4;
@@ -448,6 +544,7 @@ __global__ void __launch_bounds__(256) k_dma_gemm(GemmP p) {
                 }
             }
         }
+    }
     }
     if constexpr (CONV && NST == 2) {
         if (p.gn_part) {
