@@ -20,30 +20,6 @@
 #define ATTN_WG_PER_CU 4      // workgroups per CU the register allocation is capped for
 #endif
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-// Two exponentials at once with the packed fp32 ALU ops (v_pk_mul/fma/add_f32): element for element the operations of
-// include/var_math.h's vm_exp in the same order, so the results are bit-identical to it for every non-NaN input (the scores fed
-// here are finite or -inf).  The scaling by 2^n uses v_ldexp_f32, exact like the multiplication it replaces (results are normal).
-// About half of this kernel's non-matrix instructions were the 16 scalar exponentials per key tile.
-__device__ __forceinline__ f32x2 vh_exp_pair(f32x2 x) {
-    const f32x2 xc = {__builtin_fminf(x[0], 88.0f), __builtin_fminf(x[1], 88.0f)};
-    const f32x2 t = xc * 1.44269504088896341f;
-    const f32x2 n = {__builtin_rintf(t[0]), __builtin_rintf(t[1])};
-    f32x2 r = __builtin_elementwise_fma(n, (f32x2)(-0.693145751953125f), xc);
-    r = __builtin_elementwise_fma(n, (f32x2)(-1.42860682030941723212e-6f), r);
-    f32x2 q = (f32x2)(1.9875691500e-4f);
-    q = __builtin_elementwise_fma(q, r, (f32x2)(1.3981999507e-3f));
-    q = __builtin_elementwise_fma(q, r, (f32x2)(8.3334519073e-3f));
-    q = __builtin_elementwise_fma(q, r, (f32x2)(4.1665795894e-2f));
-    q = __builtin_elementwise_fma(q, r, (f32x2)(1.6666665459e-1f));
-    q = __builtin_elementwise_fma(q, r, (f32x2)(5.0000001201e-1f));
-    const f32x2 y = __builtin_elementwise_fma(q, r * r, r) + 1.0f;
-    f32x2 o;
-    o[0] = (x[0] > -87.0f) ? __builtin_ldexpf(y[0], (int)n[0]) : 0.0f;
-    o[1] = (x[1] > -87.0f) ? __builtin_ldexpf(y[1], (int)n[1]) : 0.0f;
-    return o;
-}
-
 template <int E>
 __device__ __forceinline__ void swap_pair(f32x16& p) {      // registers (E, E+1): afterwards E = keys (2s,2s+1), E+1 = keys (2s+4, 2s+5)
     auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(p[E]), __float_as_uint(p[E + 1]), false, false);

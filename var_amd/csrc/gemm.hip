@@ -401,7 +401,10 @@ __global__ void __launch_bounds__(256) k_dma_gemm(GemmP p) {
 #pragma unroll
                 for (int i = 0; i < TMW; ++i) {
                     f32x4 v = acc[i][j] + b4;
-                    if (p.epi == VARHIP_EPI_GELU) { v[0] = vm_gelu_tanh(v[0]); v[1] = vm_gelu_tanh(v[1]); v[2] = vm_gelu_tanh(v[2]); v[3] = vm_gelu_tanh(v[3]); }
+                    if (p.epi == VARHIP_EPI_GELU) {
+                        const f32x2 lo = vh_gelu_tanh_pair(f32x2{v[0], v[1]}), hi = vh_gelu_tanh_pair(f32x2{v[2], v[3]});
+                        v = f32x4{lo[0], lo[1], hi[0], hi[1]};
+                    }
                     if (res) {
                         if (gam) v = v * *(const f32x4*)(gb + (uint64_t)goff[i] + j * 64);
                         v = *(const f32x4*)(rb + (uint64_t)roff[i] + j * 64) + v;
