@@ -41,9 +41,15 @@ def main():
                     help='time every kernel family with HIP events (adds ~2 %% to a step); default: only the dominant kernel of the roofline object')
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` outside a torchrun environment: start the N ranks ourselves.  Nothing above or below this point in
+    # THIS process touches a GPU — the ranks are children (python -m torch.distributed.run), rank 0 prints the JSON line.
+    from var_amd import launch
+    if args.gpus > 1 and not launch.under_launcher():
+        sys.exit(launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+
     import torch
     from var_amd import dist, hip
-    from var_amd.detinit import fill_module_
+    from var_amd.detinit import fill_module_device_ as fill_module_      # the detinit values, computed on the GPU (bit-identical to the numpy generator)
     from var_amd.multi import sample_sharded
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -53,7 +59,7 @@ def main():
         torch.cuda.set_device(0)
     rank = dist.get_rank()
     dev = torch.device('cuda', torch.cuda.current_device())
-    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun --nproc-per-node {args.gpus}, or without torchrun'
 
     from models import build_vae_var
     pns = (1, 2, 3, 4, 5, 6, 8, 10, 13, 16)

@@ -87,7 +87,15 @@ int varhip_gemm_qkv_f32(const float* A, int64_t lda, const float* W, int64_t ldw
 /* ---- attention of l new queries over curL cached keys (no mask: block-causal by construction) -----------
  * out[b][t][h*64+c] = sum_j softmax_j(q[b][t][h] . k[b][h][j]) v[b][h][j][c],  j < curL
  * replaces slow_attn / flash_attn_func / memory_efficient_attention at basic_var.py:111-117 (head_dim 64, scale 1:
- * the scale is already folded into q by varhip_qkv_prep_f32). */
+ * the scale is already folded into q by varhip_qkv_prep_f32).
+ * Arithmetic contract (what makes the GPU result reproducible bit for bit by oracle/var_oracle.c):
+ *   - the running-maximum recurrence over tiles of 32 keys: m' = max(m, max_tile s), a = e(m - m'), l = l a + sum p, O = O a + P V,
+ *     p = e(s - m'), with e = vm_exp_le0 of include/var_math.h;
+ *   - every dot product (64 channels of q.k; the 32 keys of a tile in p.v) is one fp32 fma chain in the 4-interleaved order
+ *     0,4,1,5,2,6,3,7, 8,12,9,13, ... (inside each group of eight: j, j+4) — the order in which an MFMA 32x32x2 consumes operands
+ *     that both lane halves read as 16 contiguous bytes;
+ *   - l is kept as four partial sums over the keys with equal ((key >> 2) & 1, key & 1), ascending, added as (S00 + S01) + (S10 + S11);
+ *   - out = O * (1 / l). */
 int varhip_attn_cached_f32(const float* q, const float* kcache, const float* vcache, float* out,
                            int B2, int l, int H, int curL, int Lmax, varhip_stream_t stream);
 
@@ -244,6 +252,10 @@ int varhip_smooth_select_f32(const float* logits, const int64_t* gt, const int32
 /* ---- nearest-codebook lookup (encode side; quant.py:150-157) --------------------------------------------
  * idx[n] = argmin_v ( |z_n|^2 + |e_v|^2 - 2 z_n.e_v ), first index on ties; z: [N][Cv], codebook: [V][Cv] */
 int varhip_nearest_code_f32(const float* z, const float* codebook, int64_t* idx_out, int N, int V, int Cv, varhip_stream_t stream);
+
+/* the same lookup for VectorQuantizer2(using_znorm=True) (quant.py:151-153): idx[n] = argmax_v (z_n / max(|z_n|,1e-12)) . (e_v / max(|e_v|,1e-12)),
+ * first index on ties; every element is divided by its vector's norm before the (c-ascending fma) dot product, as F.normalize does */
+int varhip_nearest_code_cos_f32(const float* z, const float* codebook, int64_t* idx_out, int N, int V, int Cv, varhip_stream_t stream);
 
 /* ---- per-kernel timing (bench.py's roofline leg) -----------------------------------------------------------
  * When enabled, every launch is bracketed by hipEvents on its own stream and its algorithmic FLOPs and bytes are

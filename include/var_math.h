@@ -46,6 +46,33 @@ VM_FN float vm_exp(float x) {
     return y * s.f;
 }
 
+/* e^x for x <= 0 — the softmax numerators of the attention kernel, which are taken relative to the running maximum.
+ * Same reduction and polynomial as vm_exp, shaped so that a 64-lane wave spends as few vector instructions on it as possible
+ * (they are paid in matrix-pipe time next to fp32 MFMAs):
+ *   - x is clamped below at -87: the result is never 0 or subnormal (>= 1.6e-38), so the final scaling by 2^n is an integer
+ *     add into the exponent field (no ldexp, no select);
+ *   - n = round(x * log2 e) comes out of ONE fma against the 1.5*2^23 constant (its low mantissa bits are n), instead of
+ *     multiply + rint + float->int conversion.
+ * NaN -> the clamp returns -87's value; the callers never produce NaN (scores are finite or -inf). */
+VM_FN float vm_exp_le0(float x) {
+    x = vm_max(x, -87.0f);
+    const float t = vm_fma(x, 1.44269504088896341f, 12582912.0f);
+    const float n = t - 12582912.0f;
+    float r = vm_fma(n, -0.693145751953125f, x);
+    r = vm_fma(n, -1.42860682030941723212e-6f, r);
+    float p = 1.9875691500e-4f;
+    p = vm_fma(p, r, 1.3981999507e-3f);
+    p = vm_fma(p, r, 8.3334519073e-3f);
+    p = vm_fma(p, r, 4.1665795894e-2f);
+    p = vm_fma(p, r, 1.6666665459e-1f);
+    p = vm_fma(p, r, 5.0000001201e-1f);
+    union { float f; uint32_t u; } y, tt;
+    y.f = vm_fma(p, r * r, r) + 1.0f;
+    tt.f = t;
+    y.u = y.u + (tt.u << 23);          /* 12582912.0f == 0x4B400000: (bits << 23) keeps exactly n << 23 (mod 2^32) */
+    return y.f;
+}
+
 /* ln(x) for x > 0, relative error ~1 ulp (Cephes logf), from integer exponent extraction + fma polynomial only; x <= 0 or
  * subnormal -> -inf, NaN -> NaN, +inf -> +inf.  Used by the gumbel noise -log(Exp(1)) of the more_smooth path (helpers.py:26). */
 VM_FN float vm_log(float x) {

@@ -236,8 +236,13 @@ int varref_adaln_block_f32(float* x, float* x2, float* xn, float* q, float* att,
     return varref_gemm_nt_f32(hid, hidden, fc2_w, hidden, fc2_b, x, C, M, C, hidden, EPI_RESID, x2, C, g2, ld_ada, l, 0, 1, 0, 0, 0);
 }
 
-/* slow_attn / SDPA without mask over the cached keys (basic_var.py:111-117).  Row sum of the softmax numerators:
- * (sum over even key positions) + (sum over odd key positions), each ascending — see DESIGN.md §Numerics. */
+/* slow_attn / SDPA without mask over the cached keys (basic_var.py:111-117).
+ * Summation orders (include/var_hip.h, varhip_attn_cached_f32): a dot product over k = 0..63 (q.k) or over the 32 keys of a tile
+ * (p.v) is ONE fma chain in the "4-interleaved" order 0,4,1,5,2,6,3,7, 8,12,9,13, ... (inside every group of eight: j, j+4 for
+ * j = 0..3).  Row sum of the softmax numerators: four partial sums S[h][x] over the keys with ((key >> 2) & 1) == h and
+ * (key & 1) == x, each ascending; l = (S[0][0] + S[0][1]) + (S[1][0] + S[1][1]).  The exponential is vm_exp_le0
+ * (include/var_math.h); the output is acc * (1 / l).  See DESIGN.md §Numerics. */
+static inline int il4(int i) { return (i & ~7) + ((i & 1) << 2) + ((i & 7) >> 1); }      /* position i of the chain -> index */
 int varref_attn_cached_f32(const float* q, const float* kcache, const float* vcache, float* out,
                            int B2, int l, int H, int curL, int Lmax) {
     if (curL <= 0 || curL > Lmax) return VARHIP_EINVAL;
@@ -249,37 +254,43 @@ int varref_attn_cached_f32(const float* q, const float* kcache, const float* vca
             const float* Vv = vcache + ((int64_t)b * H + h) * Lmax * 64;
             /* The reference runs flash_attn_func / SDPA here; both are the running-max ("online softmax") recurrence with an
              * implementation-defined tile.  This restatement fixes the tile at 32 keys:
-             *   m' = max(m, max_tile s); a = exp(m - m'); l = l*a + sum p; O = O*a + sum p v,  p = exp(s - m'),
-             * the row sum kept as two partial sums (even / odd key positions) that are added at the end. */
+             *   m' = max(m, max_tile s); a = exp(m - m'); l = l*a + sum p; O = O*a + sum p v,  p = exp(s - m')
+             * (a == 1 exactly when the maximum stands, so rescaling every tile and rescaling only when it moved are the same bits). */
             for (int t = 0; t < l; ++t) {
                 const float* qr = q + ((int64_t)b * l + t) * C + h * 64;
-                float m = -INFINITY, le = 0.0f, lo = 0.0f;
-                float acc[64], s[32];
+                float m = -INFINITY, ls[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
+                float acc[64], s[32], pj[32];
                 for (int c = 0; c < 64; ++c) acc[c] = 0.0f;
                 for (int j0 = 0; j0 < curL; j0 += 32) {
                     const int nj = curL - j0 < 32 ? curL - j0 : 32;
                     float tmax = -INFINITY;
                     for (int jj = 0; jj < nj; ++jj) {
                         float a = 0.0f;
-                        for (int d = 0; d < 64; ++d) a = vm_fma(K[(int64_t)(j0 + jj) * 64 + d], qr[d], a);
+                        for (int i = 0; i < 64; ++i) { const int d = il4(i); a = vm_fma(K[(int64_t)(j0 + jj) * 64 + d], qr[d], a); }
                         s[jj] = a; tmax = vm_max(tmax, a);
                     }
                     const float mnew = vm_max(m, tmax);
-                    const float alpha = vm_exp(m - mnew);
+                    const float alpha = vm_exp_le0(m - mnew);
                     m = mnew;
-                    le = le * alpha; lo = lo * alpha;
+                    ls[0][0] = ls[0][0] * alpha; ls[0][1] = ls[0][1] * alpha; ls[1][0] = ls[1][0] * alpha; ls[1][1] = ls[1][1] * alpha;
                     for (int c = 0; c < 64; ++c) acc[c] = acc[c] * alpha;
-                    for (int jj = 0; jj < nj; ++jj) {
-                        const float pj = vm_exp(s[jj] - m);
-                        if ((j0 + jj) & 1) lo = lo + pj; else le = le + pj;
+                    for (int jj = 0; jj < nj; ++jj) {                              /* row sums: ascending keys inside each class */
+                        const int key = j0 + jj;
+                        pj[jj] = vm_exp_le0(s[jj] - m);
+                        ls[(key >> 2) & 1][key & 1] = ls[(key >> 2) & 1][key & 1] + pj[jj];
+                    }
+                    for (int i = 0; i < 32; ++i) {                                 /* p.v: 4-interleaved key order (tile starts are multiples of 32) */
+                        const int jj = il4(i);
+                        if (jj >= nj) continue;                                    /* keys past curL do not exist (the kernel adds p = 0 times v = 0) */
+                        const float pv = pj[jj];
                         const float* vr = Vv + (int64_t)(j0 + jj) * 64;
 #pragma omp simd
-                        for (int c = 0; c < 64; ++c) acc[c] = vm_fma(pj, vr[c], acc[c]);
+                        for (int c = 0; c < 64; ++c) acc[c] = vm_fma(pv, vr[c], acc[c]);
                     }
                 }
-                const float lsum = le + lo;
+                const float inv = 1.0f / ((ls[0][0] + ls[0][1]) + (ls[1][0] + ls[1][1]));
                 float* o = out + ((int64_t)b * l + t) * C + h * 64;
-                for (int c = 0; c < 64; ++c) o[c] = acc[c] / lsum;
+                for (int c = 0; c < 64; ++c) o[c] = acc[c] * inv;
             }
         }
     }
@@ -804,6 +815,27 @@ int varref_nearest_code_f32(const float* z, const float* codebook, int64_t* idx_
         idx_out[n] = best;
     }
     free(ee);
+    return 0;
+}
+
+/* using_znorm=True (reference models/quant.py:151-153): z_NC = F.normalize(z_NC, dim=-1); argmax(z_NC @ F.normalize(E.T, dim=0)).
+ * F.normalize divides every element by max(|v|_2, 1e-12); the dot product is restated as one c-ascending fma chain. */
+int varref_nearest_code_cos_f32(const float* z, const float* codebook, int64_t* idx_out, int N, int V, int Cv) {
+    float* en = (float*)malloc(sizeof(float) * V);
+    for (int v = 0; v < V; ++v) { float a = 0.0f; for (int c = 0; c < Cv; ++c) a = vm_fma(codebook[(int64_t)v * Cv + c], codebook[(int64_t)v * Cv + c], a); en[v] = vm_max(vm_sqrt(a), 1e-12f); }
+#pragma omp parallel for schedule(static)
+    for (int n = 0; n < N; ++n) {
+        const float* zr = z + (int64_t)n * Cv;
+        float zz = 0.0f; for (int c = 0; c < Cv; ++c) zz = vm_fma(zr[c], zr[c], zz);
+        const float zn = vm_max(vm_sqrt(zz), 1e-12f);
+        int best = 0; float bd = -INFINITY;
+        for (int v = 0; v < V; ++v) {
+            float dot = 0.0f; for (int c = 0; c < Cv; ++c) dot = vm_fma(zr[c] / zn, codebook[(int64_t)v * Cv + c] / en[v], dot);
+            if (dot > bd) { bd = dot; best = v; }
+        }
+        idx_out[n] = best;
+    }
+    free(en);
     return 0;
 }
 

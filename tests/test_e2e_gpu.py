@@ -31,12 +31,13 @@ def build_models(meta):
     if key in _MODELS:
         return _MODELS[key]
     from models import build_vae_var
-    from var_amd.detinit import fill_module_
+    from var_amd.detinit import fill_module_device_
     _MODELS.clear(); torch.cuda.empty_cache()
     with contextlib.redirect_stdout(io.StringIO()):
         vae, var = build_vae_var(device='cuda', patch_nums=tuple(meta['patch_nums']), depth=meta['depth'], ch=meta['ch'],
                                  shared_aln=meta['shared_aln'], attn_l2_norm=meta['attn_l2_norm'])
-    fill_module_(var, meta['depth'], 0, 'var.'); fill_module_(vae, meta['depth'], 0, 'vae.')
+    # the detinit values computed on the device (bit-identical to the numpy generator: tests/test_host_cpu.py), seconds even for d36
+    fill_module_device_(var, meta['depth'], 0, 'var.'); fill_module_device_(vae, meta['depth'], 0, 'vae.')
     _MODELS[key] = (vae.eval(), var.eval())
     return _MODELS[key]
 
@@ -107,6 +108,150 @@ def test_d16_full_pyramid_vs_reference():
     _compare('d16_full', with_oracle=False, logit_atol=1e-3)
 
 
+def test_d30_width_full_depth_vs_reference():
+    """BASELINE.json configs[3]'s model, VAR-d30 (C=1920, 30 heads, depth 30, 2.0 B parameters), first three scales, B=2: token ids
+    identical to the reference's own run (tests/golden/e2e_d30_pn123.npz), logits / f_hat / image within tolerance, and bit-exact
+    against the oracle free-running"""
+    _compare('d30_pn123', logit_atol=1e-3)
+
+
+def test_d36_width_full_depth_shared_aln_vs_reference():
+    """BASELINE.json configs[4]'s model, VAR-d36 (C=2304, 36 heads, depth 36, shared AdaLN, 2.3 B parameters), first five scales of the
+    512-pixel schedule (1,2,3,4,6), B=2: tokens identical to the reference's run, bit-exact against the oracle"""
+    _compare('d36_saln_pn12346', logit_atol=1e-3)
+
+
+@pytest.mark.parametrize('depth,saln,pns', [(30, False, (1, 2, 3, 4, 5, 6, 8, 10, 13, 16)), (36, True, (1, 2, 3, 4, 6, 9, 13, 18, 24, 32))],
+                         ids=['d30_256px', 'd36_512px'])
+def test_full_size_wide_models_properties(depth, saln, pns):
+    """BASELINE.json configs[3] / configs[4] at FULL size (VAR-d30 256x256, 10 scales, L=680; VAR-d36 512x512, patch_nums up to 32,
+    L=2240, KV cache reused across scales), B=2 on one GPU, through the size-independent checks (no oracle / reference run exists at
+    these sizes): determinism, batch-slice invariance, teacher-forced VAR.forward logits == the AR run's conditional logits bit for
+    bit (SURVEY.md §4 identity (i)), incremental f_hat == embed_to_fhat and idxBl_to_img == the AR image (identity (ii))."""
+    meta = dict(depth=depth, ch=160, patch_nums=list(pns), attn_l2_norm=True, shared_aln=saln)
+    vae, var = build_models(meta)
+    eng = var.engine()
+    V, B, L = var.V, 2, var.L
+    assert (var.C, var.num_heads, var.depth) == (64 * depth, depth, depth) and L == sum(p * p for p in pns)
+    g = torch.Generator().manual_seed(depth)
+    noise = [torch.empty(B * pn * pn, V).exponential_(1, generator=g) for pn in pns]
+    labels = torch.tensor([207, 980], device='cuda')
+    img = eng.sample(B, labels, None, 1.5, 900, 0.96, noises=noise, trace=True).clone()
+    tr = eng.last_trace
+    idx = torch.cat(tr['idx'], dim=1)
+    ar_logits = torch.cat([lg[:B] for lg in tr['logits']], dim=1)                 # conditional rows
+    f_hat = tr['f_hat'][-1].clone()
+    P = 16 * pns[-1]
+    assert img.shape == (B, 3, P, P) and torch.isfinite(img).all() and float(img.min()) >= 0 and float(img.max()) <= 1
+    assert idx.shape == (B, L) and len(torch.unique(idx)) > L // 4
+    # determinism
+    img2 = eng.sample(B, labels, None, 1.5, 900, 0.96, noises=noise, trace=True)
+    assert torch.equal(img, img2) and torch.equal(idx, torch.cat(eng.last_trace['idx'], dim=1))
+    # batch-slice invariance: image 1 alone, fed its own noise rows
+    sub = eng.sample(1, labels[1:], None, 1.5, 900, 0.96, noises=[n.view(B, -1, V)[1:].reshape(-1, V) for n in noise], trace=True)
+    assert torch.equal(torch.cat(eng.last_trace['idx'], dim=1), idx[1:]) and torch.equal(sub, img[1:])
+    # identity (i): teacher forcing over the KV cache reproduces the AR logits bit for bit
+    ms, cur = [], 0
+    for pn in pns:
+        ms.append(idx[:, cur:cur + pn * pn].contiguous()); cur += pn * pn
+    var.cond_drop_rate = 0.0
+    with torch.inference_mode():
+        tf = var(labels, vae.quantize.idxBl_to_var_input(ms))
+    assert tf.shape == (B, L, V) and torch.equal(tf, ar_logits), f'teacher-forced logits differ: max {float((tf - ar_logits).abs().max()):.3e}'
+    # identity (ii): non-incremental f_hat and image
+    with torch.inference_mode():
+        hs = [vae.quantize.embedding(i).transpose(1, 2).reshape(B, vae.Cvae, pn, pn) for i, pn in zip(ms, pns)]
+        assert torch.equal(vae.quantize.embed_to_fhat(hs, all_to_max_scale=True, last_one=True), f_hat)
+        im2 = vae.idxBl_to_img(ms, same_shape=True, last_one=True).add_(1).mul_(0.5)
+    assert torch.equal(im2, img)
+
+
+def test_engine_follows_parameter_edits():
+    """the engines key their packed weight copies on (address, version counter): autograd-visible edits are picked up by themselves,
+    `.data` edits after invalidate_engine() / load_state_dict"""
+    z, meta = util.load_case('t_pn12345')
+    vae, var = build_models(meta)
+    labels = torch.tensor(meta['labels'], device='cuda')
+    kw = dict(g_seed=3, cfg=1.5, top_k=900, top_p=0.96)
+    base = var.autoregressive_infer_cfg(2, labels, **kw).clone()
+    sd_var = {k: v.clone() for k, v in var.state_dict().items()}
+    sd_vae = {k: v.clone() for k, v in vae.state_dict().items()}
+    with torch.no_grad():
+        var.head.weight.mul_(0.5)                                                  # bumps the version counter
+    a = var.autoregressive_infer_cfg(2, labels, **kw).clone()
+    assert not torch.equal(a, base)
+    vae.decoder.conv_in.weight.data.mul_(1.5)                                      # `.data`: no counter — stale until told
+    vae.invalidate_engines()
+    b = var.autoregressive_infer_cfg(2, labels, **kw).clone()
+    assert not torch.equal(b, a)
+    var.load_state_dict(sd_var); vae.load_state_dict(sd_vae)                       # both loaders invalidate
+    assert torch.equal(var.autoregressive_infer_cfg(2, labels, **kw), base)
+    # VAR.forward outside eval() keeps the PyTorch branch (DropPath / dropout are live there), inside eval() the HIP one
+    x = torch.randn(2, var.L - var.first_l, var.Cvae, device='cuda')
+    var.cond_drop_rate = 0.0
+    with torch.no_grad():
+        ev = var(labels, x)
+        var.train(); tr_ = var(labels, x); var.eval()
+    assert ev.shape == tr_.shape == (2, var.L, var.V) and torch.isfinite(tr_).all()
+
+
+def test_inpainting_more_smooth_vs_reference(golden_dir):
+    """VAR.inpainting(more_smooth=True) with no fully kept scale (var.py:332-341): equals autoregressive sampling with more_smooth on the
+    same noise bit for bit (the kept tokens never reach f_hat on that branch), and the reference's run within the gumbel tolerance;
+    a fully kept scale is refused (undefined in the reference)."""
+    import json
+    from tests.test_oracle_vs_golden import regen_smooth_noise
+    z = np.load(f'{golden_dir}/inpaint_ms_t_pn12345.npz')
+    meta = json.loads(str(z['meta']))
+    vae, var = build_models(meta)
+    n1, n2 = regen_smooth_noise(meta, z)
+    n1 = [torch.from_numpy(a) for a in n1]; n2 = [torch.from_numpy(a) for a in n2]
+    labels = torch.tensor(meta['labels'], device='cuda')
+    gt, mask = torch.from_numpy(z['gt'].astype(np.int64)).cuda(), torch.from_numpy(z['mask']).cuda()
+    eng = var.engine()
+    img = eng.sample(2, labels, None, meta['cfg'], meta['top_k'], meta['top_p'], noises=n1, gumbel_noises=n2, more_smooth=True, gt_tokens=gt, keep_mask=mask).clone()
+    ar = eng.sample(2, labels, None, meta['cfg'], meta['top_k'], meta['top_p'], noises=n1, gumbel_noises=n2, more_smooth=True)
+    assert torch.equal(img, ar)
+    ok, m = util.diff_report('inpaint more_smooth image vs reference', img.cpu().numpy(), z['img'], atol=2e-3); print(m); assert ok, m
+    out = var.inpainting(gt, mask, label=labels, g_seed=5, cfg=1.5, top_k=900, top_p=0.96, more_smooth=True)
+    assert out.shape == img.shape and torch.isfinite(out).all()
+    full = mask.clone(); full[:, :1] = True
+    with pytest.raises(NotImplementedError):
+        var.inpainting(gt, full, label=labels, g_seed=5, more_smooth=True)
+
+
+def test_znorm_quantizer_on_hip_vs_reference(golden_dir):
+    """VectorQuantizer2(using_znorm=True).f_to_idxBl_or_fhat on HIP (cosine arg-max kernel, quant.py:151-153) against the reference's
+    tokens and f_hat's (tests/golden/nearest_code_cos.npz) and against the oracle twin on every scale's queries"""
+    import json
+    z = np.load(f'{golden_dir}/nearest_code_cos.npz')
+    meta = json.loads(str(z['meta']))
+    from models import VQVAE
+    from var_amd.detinit import fill_module_device_
+    pns = tuple(meta['patch_nums'])
+    with contextlib.redirect_stdout(io.StringIO()):
+        vae = VQVAE(vocab_size=4096, z_channels=32, ch=meta['ch'], using_znorm=True, test_mode=True, share_quant_resi=4, v_patch_nums=pns).cuda().eval()
+    fill_module_device_(vae, meta['depth'], 0, 'vae.')
+    f = torch.from_numpy(z['f']).cuda()
+    with torch.inference_mode():
+        idx = vae.quantize.f_to_idxBl_or_fhat(f, to_fhat=False)
+        fh = vae.quantize.f_to_idxBl_or_fhat(f, to_fhat=True)
+    for si in range(len(pns)):
+        ok, m = util.diff_report(f'znorm tokens s{si} vs reference', idx[si].cpu().numpy().astype(np.int32), z[f'idx_s{si}']); print(m); assert ok, m
+        ok, m = util.diff_report(f'znorm f_hat s{si} vs reference', fh[si].cpu().numpy(), z[f'f_hat_s{si}'], atol=2e-5, rtol=1e-5); print(m); assert ok, m
+    util.ensure_oracle_built()
+    from oracle.var_oracle import lib, _p
+    from var_amd import hip
+    g = torch.Generator().manual_seed(1)
+    q = torch.randn(777, 32, generator=g)
+    cb = vae.quantize.embedding.weight.detach()
+    out = torch.empty(777, dtype=torch.int64, device='cuda')
+    hip.call('nearest_code_cos_f32', q.cuda(), cb, out, 777, 4096, 32)
+    want = np.zeros(777, np.int64)
+    assert lib()['nearest_code_cos_f32'](_p(q.numpy()), _p(np.ascontiguousarray(cb.cpu().numpy())), _p(want), 777, 4096, 32) == 0
+    assert np.array_equal(out.cpu().numpy(), want)
+
+
 def test_demo_sample_calling_convention():
     """The reference's harness (demo_sample.py:43-68) calls the model inside inference_mode + fp16 autocast with 8 labels,
     cfg=4, top_k=900, top_p=0.95: the HIP path computes in fp32 regardless, so the enclosing autocast must not change a bit;
@@ -164,8 +309,8 @@ def test_public_api_and_properties():
 
 
 def test_incremental_fhat_equals_embed_to_fhat_and_decoder_api():
-    """SURVEY.md §4 identity (ii): the AR loop's accumulated f_hat == VectorQuantizer2.embed_to_fhat on its tokens (PyTorch,
-    tolerance: different rounding order), and VQVAE.fhat_to_img (HIP decoder via the public API) reproduces the loop's image."""
+    """SURVEY.md §4 identity (ii): the AR loop's accumulated f_hat == VectorQuantizer2.embed_to_fhat on its tokens (both on the HIP
+    quantizer kernels: bit-identical), and VQVAE.fhat_to_img (HIP decoder via the public API) reproduces the loop's image."""
     z, meta = util.load_case('t_pn12345')
     vae, var = build_models(meta)
     img, tr = hip_run(meta, z)
@@ -176,8 +321,11 @@ def test_incremental_fhat_equals_embed_to_fhat_and_decoder_api():
     with torch.inference_mode():
         hs = [vae.quantize.embedding(i).transpose(1, 2).reshape(len(meta['labels']), vae.Cvae, pn, pn) for i, pn in zip(ms, meta['patch_nums'])]
         f_ref = vae.quantize.embed_to_fhat(hs, all_to_max_scale=True, last_one=True)
-        ok, m = util.diff_report('f_hat incremental vs embed_to_fhat', tr['f_hat'][-1], f_ref.cpu().numpy(), atol=2e-5, rtol=1e-5)
+        ok, m = util.diff_report('f_hat incremental vs embed_to_fhat (HIP both: exact)', tr['f_hat'][-1], f_ref.cpu().numpy())
         print(m); assert ok, m
+        f_list = vae.quantize.embed_to_fhat(hs, all_to_max_scale=True, last_one=False)
+        for si in range(len(hs)):
+            ok, m = util.diff_report(f'embed_to_fhat list s{si} (exact)', f_list[si].cpu().numpy(), tr['f_hat'][si]); assert ok, m
         im2 = vae.fhat_to_img(torch.from_numpy(tr['f_hat'][-1]).cuda()).add_(1).mul_(0.5)
     ok, m = util.diff_report('fhat_to_img API vs loop image', im2.cpu().numpy(), img, atol=1e-6)
     print(m); assert ok, m
@@ -215,7 +363,7 @@ def test_inpainting_vs_reference_and_oracle(name, golden_dir):
     for pn in meta['patch_nums']:
         ms.append(gt[:, cur:cur + pn * pn]); cur += pn * pn
     ref_img = vae.idxBl_to_img(ms, same_shape=True, last_one=True).add_(1).mul_(0.5)
-    ok, m = util.diff_report('all-kept inpainting == idxBl_to_img', full.cpu().numpy(), ref_img.cpu().numpy(), atol=2e-5); print(m); assert ok, m
+    ok, m = util.diff_report('all-kept inpainting == idxBl_to_img (exact)', full.cpu().numpy(), ref_img.cpu().numpy()); print(m); assert ok, m
     with pytest.raises(ValueError):
         var.inpainting(gt, mask[:, :-1], label=labels)
 

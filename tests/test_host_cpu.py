@@ -258,3 +258,68 @@ def test_shard_range_rejects_ragged_batches():
     assert shard_range(512, 3, 8) == (192, 256)
     with pytest.raises(ValueError):
         shard_range(10, 0, 4)
+
+
+# ---- rank launcher (what `python bench.py --gpus N` uses outside torchrun) -----------------------------------------------------
+_STUB_RANK = r'''
+import json, os, sys
+import torch.distributed as tdist
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+assert os.environ['MASTER_ADDR'] == '127.0.0.1' and os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY') == '0'
+tdist.init_process_group('gloo')                      # the stub stands in for bench.py's RCCL group; rendezvous must work
+assert tdist.get_world_size() == world == int(sys.argv[sys.argv.index('--gpus') + 1])
+tdist.barrier()
+if 'fail' in sys.argv and rank == world - 1:
+    sys.exit(7)
+if rank == 0:
+    print(json.dumps({'n_gpus': world, 'argv': sys.argv[1:]}), flush=True)
+tdist.destroy_process_group()
+'''
+
+
+def test_spawn_ranks_starts_n_ranks_and_relays_rank0_line(tmp_path):
+    from var_amd import launch
+    script = tmp_path / 'stub_rank.py'
+    script.write_text(_STUB_RANK)
+    code = f'import sys; sys.path.insert(0, {ROOT!r}); from var_amd import launch; ' \
+           f'sys.exit(launch.spawn_ranks({str(script)!r}, ["--gpus", "2", "--steps", "1"], 2, device_count=lambda: 2, timeout=200))'
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=240, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    import json
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['argv'] == ['--gpus', '2', '--steps', '1']
+    # a failing rank makes the launcher's exit code non-zero; too few GPUs is refused before anything starts
+    code_fail = code.replace('"--steps", "1"', '"fail"')
+    out = subprocess.run([sys.executable, '-c', code_fail], capture_output=True, text=True, timeout=240, env=env)
+    assert out.returncode != 0
+    assert launch.spawn_ranks(str(script), ['--gpus', '4'], 4, device_count=lambda: 1) == 2
+    assert launch.under_launcher({'RANK': '0', 'WORLD_SIZE': '2'}) and not launch.under_launcher({})
+
+
+def test_bench_self_launches_when_asked_for_more_gpus_than_ranks(monkeypatch):
+    """bench.py --gpus 2 outside torchrun must go through the launcher (and therefore fail here: this container has no GPU), never run
+    one rank and report n_gpus 1."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                         capture_output=True, text=True, timeout=240, env=env)
+    if torch.cuda.device_count() < 2:
+        assert out.returncode == 2 and 'ranks requested' in out.stderr and not any(ln.startswith('{') for ln in out.stdout.splitlines())
+
+
+def test_device_side_detinit_matches_numpy():
+    """var_amd.detinit.fill_module_device_ (torch int64 ops where the parameter lives; what the 2 B-parameter GPU tests use) must
+    produce the bits of the numpy generator the fixtures were made with"""
+    from var_amd.detinit import fill_module_, fill_module_device_, hash_uniform, hash_uniform_torch
+    a = hash_uniform('var.blocks.0.attn.proj.weight', (1 << 18) + 5, 3)
+    b = hash_uniform_torch('var.blocks.0.attn.proj.weight', (1 << 18) + 5, 3, 'cpu', chunk=1 << 16).numpy()
+    assert np.array_equal(a, b)
+    v1, m1 = _quiet_build(depth=2, ch=32, patch_nums=(1, 2, 3), shared_aln=True)
+    v2, m2 = _quiet_build(depth=2, ch=32, patch_nums=(1, 2, 3), shared_aln=True)
+    fill_module_(m1, 2, 0, 'var.'); fill_module_device_(m2, 2, 0, 'var.')
+    fill_module_(v1, 2, 0, 'vae.'); fill_module_device_(v2, 2, 0, 'vae.')
+    for x, y in ((m1, m2), (v1, v2)):
+        for (k, p), q in zip(x.state_dict().items(), y.state_dict().values()):
+            assert torch.equal(p, q), k

@@ -203,3 +203,54 @@ def test_sampler_vectors(golden_dir):
 def test_sampler_rejects_bad_args():
     assert lib()['cfg_sample_f32'](None, None, None, None, 1, 1, 1000, 0.0, 0, 0.0) == -1     # V % 256
     assert lib()['cfg_sample_f32'](None, None, None, None, 1, 1, 4096, 0.0, 5000, 0.0) == -1  # top_k > V
+
+
+def test_inpainting_more_smooth_case(golden_dir):
+    """VAR.inpainting(more_smooth=True) with no fully kept scale (fork, var.py:332-341): the soft embeddings come from the filtered
+    logits alone, so the run equals autoregressive_infer_cfg(more_smooth=True) on the same labels and noise; vs the reference run."""
+    z = np.load(f'{golden_dir}/inpaint_ms_t_pn12345.npz')
+    meta = json.loads(str(z['meta']))
+    orc = _oracle(meta)
+    n1, n2 = regen_smooth_noise(meta, z)
+    r = orc.run(meta['labels'], n1, meta['cfg'], meta['top_k'], meta['top_p'], more_smooth=True, gumbel_noises=n2,
+                gt_tokens=z['gt'].astype(np.int64), keep_mask=z['mask'])
+    r0 = orc.run(meta['labels'], n1, meta['cfg'], meta['top_k'], meta['top_p'], more_smooth=True, gumbel_noises=n2)
+    assert np.array_equal(r['f_hat'][-1], r0['f_hat'][-1]), 'the kept tokens must not reach f_hat on the more_smooth branch'
+    assert np.array_equal(r['idx'][z['mask']], z['gt'][z['mask']])
+    ok, m = util.diff_report('inpaint more_smooth f_hat', r['f_hat'][-1], z['f_hat'], atol=5e-3, rtol=1e-3); print(m); assert ok, m
+    ok, m = util.diff_report('inpaint more_smooth image', r['img'], z['img'], atol=2e-3); print(m); assert ok, m
+
+
+def test_nearest_code_cosine_vs_reference(golden_dir):
+    """VectorQuantizer2(using_znorm=True).f_to_idxBl_or_fhat (quant.py:151-153): the oracle's cosine arg-max on the first scale's
+    queries (area pooling to 1x1 == spatial mean) against the reference's tokens; margins of the fixture are >= 1e-2."""
+    z = np.load(f'{golden_dir}/nearest_code_cos.npz')
+    meta = json.loads(str(z['meta']))
+    from var_amd import shapes
+    from var_amd.detinit import make_state_dict
+    sd = make_state_dict(shapes.vae_shapes(ch=meta['ch'], patch_nums=tuple(meta['patch_nums'])), depth=meta['depth'], seed=0, prefix='vae.')
+    zq = np.ascontiguousarray(z['f'].mean(axis=(2, 3)), dtype=np.float32)
+    out = np.zeros(zq.shape[0], np.int64)
+    assert lib()['nearest_code_cos_f32'](_p(zq), _p(np.ascontiguousarray(sd['quantize.embedding.weight'])), _p(out), zq.shape[0], 4096, 32) == 0
+    assert float(z['margin_s0'].min()) > 1e-3
+    assert np.array_equal(out.astype(np.int32), z['idx_s0'][:, 0])
+    # and the whole residual loop in our PyTorch module on CPU (the HIP routing of the same loop is compared in tests/test_e2e_gpu.py)
+    import contextlib, io
+    import torch
+    from models import VQVAE
+    pns = tuple(meta['patch_nums'])
+    with contextlib.redirect_stdout(io.StringIO()):
+        vae = VQVAE(vocab_size=4096, z_channels=32, ch=meta['ch'], using_znorm=True, test_mode=True, share_quant_resi=4, v_patch_nums=pns)
+    vae.load_state_dict({**{k: torch.from_numpy(v) for k, v in sd.items()}, 'quantize.ema_vocab_hit_SV': vae.quantize.ema_vocab_hit_SV}, strict=True)
+    with torch.no_grad():
+        idx = vae.quantize.f_to_idxBl_or_fhat(torch.from_numpy(z['f']), to_fhat=False)
+    for si, i in enumerate(idx):
+        assert np.array_equal(i.numpy().astype(np.int32), z[f'idx_s{si}']), si
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize('name', ['d30_pn123', 'd36_saln_pn12346'])
+def test_wide_model_fixtures(name):
+    """the widths of BASELINE.json configs[3] (VAR-d30, C=1920) and configs[4] (VAR-d36, C=2304, shared AdaLN): oracle vs the
+    reference's own run at full depth on the first scales; teacher-forced only (about a minute each, 8-9 GB of weights)"""
+    _check_case(name, logit_atol=1e-3, img_atol=1e-3, free_running=False)

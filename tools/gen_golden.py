@@ -51,6 +51,10 @@ CASES = {
     't_nofilter':    dict(depth=2, ch=32, patch_nums=(1, 2, 3), attn_l2_norm=True, shared_aln=False, labels=(100, 200), seed=5, cfg=0.0, top_k=0, top_p=0.0, full_logits=False),
     't_b3_pn1234':   dict(depth=2, ch=32, patch_nums=(1, 2, 3, 4), attn_l2_norm=True, shared_aln=False, labels=(0, 500, 999), seed=123, cfg=3.0, top_k=600, top_p=0.5, full_logits=False),
     'd16_pn123':     dict(depth=16, ch=160, patch_nums=(1, 2, 3), attn_l2_norm=True, shared_aln=False, labels=(3, 7), seed=0, cfg=1.5, top_k=900, top_p=0.96, full_logits=False),
+    # the widths of BASELINE.json configs[3] / configs[4]: VAR-d30 (C=1920, 30 heads, 2.0 B parameters) on the first three scales and
+    # VAR-d36 (C=2304, 36 heads, shared AdaLN, 2.3 B parameters) on the first five scales of the 512-pixel schedule (utils/arg_util.py:244-251)
+    'd30_pn123':     dict(depth=30, ch=160, patch_nums=(1, 2, 3), attn_l2_norm=True, shared_aln=False, labels=(3, 7), seed=0, cfg=1.5, top_k=900, top_p=0.96, full_logits=False),
+    'd36_saln_pn12346': dict(depth=36, ch=160, patch_nums=(1, 2, 3, 4, 6), attn_l2_norm=True, shared_aln=True, labels=(980, 437), seed=1, cfg=1.5, top_k=900, top_p=0.96, full_logits=False),
     'd16_full':      dict(depth=16, ch=160, patch_nums=(1, 2, 3, 4, 5, 6, 8, 10, 13, 16), attn_l2_norm=True, shared_aln=False, labels=(0, 7), seed=0, cfg=1.5, top_k=900, top_p=0.96, full_logits=False),
 }
 
@@ -167,6 +171,62 @@ def run_inpaint():
         rec.update(noise_head=np.stack(nh), noise_sum=np.array(ns), meta=np.array(json.dumps(meta)))
         np.savez_compressed(os.path.join(GOLD, f'{name}.npz'), **rec)
         print(f'[gen_golden] {name}: kept {int(mask.sum())}/{mask.numel()} tokens, {int((rec["idx"] != rec["gt"]).sum())} resampled differently', flush=True)
+
+
+def run_inpaint_more_smooth():
+    """VAR.inpainting(more_smooth=True) (fork, var.py:332-341) with no fully kept scale: the embeddings come from the gumbel softmax of the
+    filtered logits alone (the kept tokens only reach `final_tokens`, which that branch does not read); two Exp(1) fills per scale."""
+    cfg = dict(CASES['t_pn12345']); seed = 13
+    vae, var = build_reference(cfg)
+    z = np.load(os.path.join(GOLD, 'e2e_t_pn12345.npz'))
+    gt = torch.from_numpy(z['idx'].astype(np.int64))
+    B, L = gt.shape
+    g = torch.Generator(); g.manual_seed(12)
+    mask = torch.rand(B, L, generator=g) < 0.5
+    mask[:, 0] = False                                     # scale 0 has one token per image: never fully kept
+    fhats = []
+    orig_next = vae.quantize.get_next_autoregressive_input
+    def get_next(si, SN, f_hat, h):
+        f, nxt = orig_next(si, SN, f_hat, h); fhats.append(f.detach().clone()); return f, nxt
+    vae.quantize.get_next_autoregressive_input = get_next
+    with torch.inference_mode():
+        img = var.inpainting(gt, mask, label=torch.tensor(cfg['labels']), g_seed=seed, cfg=cfg['cfg'], top_k=cfg['top_k'], top_p=cfg['top_p'], more_smooth=True)
+    gg = torch.Generator(); gg.manual_seed(seed)
+    heads = []
+    for pn in cfg['patch_nums']:
+        a = torch.empty(B * pn * pn, 4096).exponential_(1, generator=gg); b = torch.empty(B, pn * pn, 4096).exponential_(generator=gg)
+        heads.append(np.concatenate([a.view(-1)[:4].numpy(), b.view(-1)[:4].numpy()]))
+    meta = dict(cfg); meta.update(B=B, V=4096, seed=seed)
+    np.savez_compressed(os.path.join(GOLD, 'inpaint_ms_t_pn12345.npz'), gt=gt.numpy().astype(np.int32), mask=mask.numpy(), img=img.numpy(),
+                        f_hat=fhats[-1].numpy(), noise_head=np.stack(heads), meta=np.array(json.dumps(meta)))
+    print(f'[gen_golden] inpaint_ms_t_pn12345: img mean {img.mean():.4f}', flush=True)
+
+
+def run_nearest_code_cos():
+    """A17 with using_znorm=True (reference models/quant.py:151-153): cosine arg-max instead of the L2 arg-min"""
+    import contextlib, io
+    from models import VQVAE
+    cfg = CASES['t_pn12345']
+    pns = tuple(cfg['patch_nums'])
+    with contextlib.redirect_stdout(io.StringIO()):
+        vae = VQVAE(vocab_size=4096, z_channels=32, ch=cfg['ch'], using_znorm=True, test_mode=True, share_quant_resi=4, v_patch_nums=pns)
+    fill_module_(vae, cfg['depth'], 0, 'vae.')
+    vae.eval()
+    P = pns[-1]
+    g = torch.Generator(); g.manual_seed(78)
+    f = torch.randn(3, 32, P, P, generator=g) * 1.5
+    with torch.inference_mode():
+        idx = vae.quantize.f_to_idxBl_or_fhat(f, to_fhat=False)
+        fh = vae.quantize.f_to_idxBl_or_fhat(f, to_fhat=True)
+    rec = dict(f=f.numpy(), meta=np.array(json.dumps(dict(cfg))))
+    for si, (i, h) in enumerate(zip(idx, fh)):
+        rec[f'idx_s{si}'] = i.numpy().astype(np.int32); rec[f'f_hat_s{si}'] = h.numpy()
+    # how decisive the arg-max is: margin between the best and second-best cosine of the first scale's queries
+    zq = torch.nn.functional.normalize(f.mean(dim=(2, 3)), dim=-1) @ torch.nn.functional.normalize(vae.quantize.embedding.weight.data.T, dim=0)
+    top2 = zq.topk(2, dim=1).values
+    rec['margin_s0'] = (top2[:, 0] - top2[:, 1]).numpy()
+    np.savez_compressed(os.path.join(GOLD, 'nearest_code_cos.npz'), **rec)
+    print('[gen_golden] nearest_code_cos done; s0 margins', rec['margin_s0'], flush=True)
 
 
 def run_more_smooth():
@@ -320,6 +380,8 @@ def main():
         run_case(name, cfg)
     if not args.only or 'inpaint' in args.only: run_inpaint()
     if not args.only or 'more_smooth' in args.only: run_more_smooth()
+    if not args.only or 'inpaint_more_smooth' in args.only: run_inpaint_more_smooth()
+    if not args.only or 'nearest_code_cos' in args.only: run_nearest_code_cos()
     if not args.only or 'smooth_sampling' in args.only: run_smooth_sampling()
     if not args.only or 'encode' in args.only: run_encode()
     if not args.only or 'nearest_code' in args.only: run_nearest_code()

@@ -32,6 +32,7 @@ SIGNATURES = {
     'nchw_to_nhwc_f32':  [P, P, I, I, I],
     'nhwc_to_nchw_f32':  [P, P, I, I, I],
     'nearest_code_f32':  [P, P, P, I, I, I],
+    'nearest_code_cos_f32': [P, P, P, I, I, I],
     'token_select_i64':  [P, P, P, P, L],
     'conv3x3_s2_nhwc_f32': [P, P, P, P, I, I, I, I, I],
     'nchw_to_nhwc_pad_f32': [P, P, I, I, I, I],

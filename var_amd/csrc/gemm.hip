@@ -82,9 +82,10 @@ template <int MAXA, int PER> __device__ __forceinline__ void vh_wait_dma_and_bar
 // One LDS-DMA request in the "scalar base + 32-bit vector offset" form: 16 bytes per lane from base + voff to LDS address `lds`
 // (+ 16 * lane).  Written as inline assembly because the compiler hoists the zero-extension of the offset out of the K loop and
 // then only sees a 64-bit vector address (v_lshl_add_u64 per request).  The waitcnt pass does not see these requests: every
-// barrier that publishes a tile spells out its own s_waitcnt vmcnt (vh_waitcnt_barrier).
+// barrier that publishes a tile spells out its own s_waitcnt vmcnt (vh_waitcnt_barrier).  M0 (the LDS destination) is written
+// inside the statement that uses it and named in the clobber list, so the compiler never assumes a value of its own survives.
 __device__ __forceinline__ void vh_dma16(const void* base, uint32_t voff, uint32_t lds) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(base), "s"(lds) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(base), "s"(lds) : "memory", "m0");
 }
 
 // The same through a buffer descriptor: 16 bytes per lane from rsrc.base + soff + voff.  A request whose voff lies at or beyond
@@ -93,7 +94,14 @@ __device__ __forceinline__ void vh_dma16(const void* base, uint32_t voff, uint32
 __device__ __forceinline__ void vh_dma16_buf(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff, uint32_t lds) {
     // (readfirstlane: a value the compiler computed on the vector ALU although it is wave-uniform must still reach an SGPR operand)
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
-                 : : "v"(voff), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane(soff)), "s"(__builtin_amdgcn_readfirstlane(lds)) : "memory");
+                 : : "v"(voff), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane(soff)), "s"(__builtin_amdgcn_readfirstlane(lds)) : "memory", "m0");
+}
+
+// The same with a full 64-bit per-lane source address (the nearest-2x GATHER mode, whose source is not "base + offset").  Every LDS-DMA
+// of this file is one of these three statements: each writes M0 itself and declares it clobbered, and the compiler's own
+// M0-tracking builtin (__builtin_amdgcn_global_load_lds) is not used next to them.
+__device__ __forceinline__ void vh_dma16_ptr(const void* src, uint32_t lds) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds) : "memory", "m0");
 }
 
 // GATHER: the nearest-2x gather mode of the convolution (up2 == 1; tests and the oracle comparison only — the decoder runs the
@@ -221,8 +229,7 @@ __global__ void __launch_bounds__(256) k_dma_gemm(GemmP p) {
                 const int yy = a_y[i] + dy, xx = a_x[i] + dx;
                 const bool ok = (unsigned)yy < (unsigned)cv_hlim && (unsigned)xx < (unsigned)cv_wlim;
                 const float* src = ok ? asrc[i] + (((int64_t)a_b[i] * p.Hi + (yy >> 1)) * p.Wi + (xx >> 1)) * p.Cin + ci0 : zsrc;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(sA + i * 8 * BK), 16, 0, 0);
+                vh_dma16_ptr(src, (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(sA + i * 8 * BK));
             } else if constexpr (CONV) {
                 vh_dma16_buf(arsrc, ((abad[i] >> tap) << 31) | aoff[i], soff,
                              (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(sA + i * 8 * BK));

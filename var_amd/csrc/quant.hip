@@ -300,3 +300,44 @@ extern "C" int varhip_nearest_code_f32(const float* z, const float* codebook, in
     hipLaunchKernelGGL(k_nearest_code, dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream, z, codebook, idx_out, V, Cv);
     return vh_launch_status();
 }
+
+// cosine variant (using_znorm=True, quant.py:151-153): argmax_v  (z / max(|z|, 1e-12)) . (e_v / max(|e_v|, 1e-12)), first index on ties.
+// Every factor is rounded as F.normalize would round it (element / norm), the dot product is one c-ascending fma chain.
+__global__ void __launch_bounds__(256) k_nearest_code_cos(const float* __restrict__ z, const float* __restrict__ codebook, int64_t* __restrict__ idx_out, int V, int Cv) {
+    __shared__ float sz[64];
+    __shared__ float s_d[4]; __shared__ int s_i[4];
+    const int tid = threadIdx.x; const int64_t n = blockIdx.x;
+    if (tid < Cv) sz[tid] = z[n * Cv + tid];
+    __syncthreads();
+    float zz = 0.f;
+    for (int c = 0; c < Cv; ++c) zz = vm_fma(sz[c], sz[c], zz);
+    const float zn = vm_max(vm_sqrt(zz), 1e-12f);
+    float bd = -INFINITY; int bi = 0x7fffffff;
+    for (int v = tid; v < V; v += 256) {
+        const float* e = codebook + (int64_t)v * Cv;
+        float ee = 0.f;
+        for (int c = 0; c < Cv; ++c) ee = vm_fma(e[c], e[c], ee);
+        const float en = vm_max(vm_sqrt(ee), 1e-12f);
+        float dot = 0.f;
+        for (int c = 0; c < Cv; ++c) dot = vm_fma(sz[c] / zn, e[c] / en, dot);
+        if (dot > bd) { bd = dot; bi = v; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float od = __shfl_xor(bd, off, 64); const int oi = __shfl_xor(bi, off, 64);
+        if (od > bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+    }
+    if ((tid & 63) == 0) { s_d[tid >> 6] = bd; s_i[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w) if (s_d[w] > bd || (s_d[w] == bd && s_i[w] < bi)) { bd = s_d[w]; bi = s_i[w]; }
+        idx_out[n] = bi == 0x7fffffff ? 0 : bi;
+    }
+}
+extern "C" int varhip_nearest_code_cos_f32(const float* z, const float* codebook, int64_t* idx_out, int N, int V, int Cv, varhip_stream_t stream) {
+    if (N < 0 || V <= 0 || Cv <= 0 || Cv > 64) return VARHIP_EINVAL;
+    if (N == 0) return 0;
+    VhScope sc(VH_FAM_OTHER, (hipStream_t)stream, 4.0 * N * (double)V * Cv, 4.0 * ((double)N * Cv + (double)V * Cv));
+    hipLaunchKernelGGL(k_nearest_code_cos, dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream, z, codebook, idx_out, V, Cv);
+    return vh_launch_status();
+}

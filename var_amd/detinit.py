@@ -113,11 +113,72 @@ def make_state_dict(shapes: Mapping[str, Tuple[int, ...]], depth: int, seed: int
     return out
 
 
+def _after_fill(module) -> None:
+    """writes through state_dict() tensors bump no version counter: tell a HIP engine that may hold packed copies"""
+    for hook in ('invalidate_engine', 'invalidate_engines'):
+        if hasattr(module, hook):
+            getattr(module, hook)()
+
+
 def fill_module_(module, depth: int, seed: int = 0, prefix: str = '') -> None:
-    """Overwrite every parameter/buffer of a torch module in place from make_state_dict (strict key match)."""
+    """Overwrite every parameter/buffer of a torch module in place, key by key, from the rules of make_state_dict (strict key
+    match); numpy on the host (the form the CPU oracle and the golden generator share)."""
     import torch
     sd = module.state_dict()
-    new = make_state_dict({k: tuple(v.shape) for k, v in sd.items()}, depth=depth, seed=seed, prefix=prefix)
     with torch.no_grad():
-        for k, arr in new.items():
-            sd[k].copy_(torch.from_numpy(arr).to(sd[k].device))
+        for k, t in sd.items():
+            if k.endswith(_KEEP):
+                continue
+            arr = make_state_dict({k: tuple(t.shape)}, depth=depth, seed=seed, prefix=prefix)[k]
+            t.copy_(torch.from_numpy(arr).to(t.device))
+    _after_fill(module)
+
+
+# ---- the same values computed where the parameter lives (torch int64 ops; used for the 2 B-parameter models on the GPU box) ------
+_C1, _C2, _C3 = (c - (1 << 64) for c in (0x9E3779B97F4A7C15, 0xBF58476D1CE4E5B9, 0x94D049BB133111EB))      # as signed 64-bit
+
+
+def _lsr(x, n: int):
+    """logical right shift of an int64 tensor (torch's >> is arithmetic)"""
+    return (x >> n) & ((1 << (64 - n)) - 1)
+
+
+def _splitmix64_t(x):
+    x = x + _C1                                   # two's-complement wrap-around == the uint64 arithmetic of _splitmix64
+    x = (x ^ _lsr(x, 30)) * _C2
+    x = (x ^ _lsr(x, 27)) * _C3
+    return x ^ _lsr(x, 31)
+
+
+def hash_uniform_torch(name: str, numel: int, seed: int, device, chunk: int = 1 << 25):
+    """hash_uniform on `device` with torch integer ops: bit-identical to the numpy version (tests/test_host_cpu.py)"""
+    import torch
+    key = (np.uint64(zlib.crc32(name.encode())) << np.uint64(32)) ^ np.uint64(seed & 0xFFFFFFFF) ^ (np.uint64(len(name)) << np.uint64(56))
+    key = int(_splitmix64(np.array([key], dtype=np.uint64))[0])
+    if key >= 1 << 63: key -= 1 << 64
+    out = torch.empty(numel, dtype=torch.float32, device=device)
+    for s in range(0, numel, chunk):
+        e = min(numel, s + chunk)
+        h = _splitmix64_t(torch.arange(s, e, dtype=torch.int64, device=device) ^ key)
+        u24 = _lsr(h, 40)
+        out[s:e] = (u24 - (1 << 23)).to(torch.float32) * (2.0 ** -23)
+    return out
+
+
+def fill_module_device_(module, depth: int, seed: int = 0, prefix: str = '') -> None:
+    """fill_module_ without the host round trip: every value is produced on the parameter's own device.  Same bits."""
+    import torch
+    sd = module.state_dict()
+    with torch.no_grad():
+        for k, t in sd.items():
+            if k.endswith(_KEEP):
+                continue
+            amp, off = _rule(k, tuple(t.shape), depth)
+            if amp == 0.0 and off == 0.0:
+                raise KeyError(f'detinit: no rule for parameter {k!r} {tuple(t.shape)}')
+            u = hash_uniform_torch(prefix + k, t.numel(), seed, t.device)
+            # value = offset + amplitude * U in float32, product and sum rounded separately (as numpy does it)
+            u = u * float(np.float32(amp))
+            u = u + float(np.float32(off))
+            t.copy_(u.view(t.shape))
+    _after_fill(module)

@@ -49,6 +49,21 @@ def phi_index(si: int, S: int, K: int) -> int:
     return int(np.argmin(np.abs(ticks - si / (S - 1)))) if S > 1 else 0
 
 
+def _ver(p: torch.Tensor) -> int:
+    """version counter of a parameter; tensors created under torch.inference_mode() have none"""
+    try:
+        return p._version
+    except RuntimeError:
+        return -1
+
+
+def _signature(params) -> tuple:
+    """what the engines key their re-laid weight copies on: storage address + version counter of every parameter.  In-place writes
+    through `.data` (p.data.mul_(), p.data.copy_()) bump no counter: after such surgery call `engine.invalidate()` (VAR / VQVAE
+    do it from load_state_dict and init_weights)."""
+    return tuple((p.data_ptr(), _ver(p)) for p in params)
+
+
 def _chk(t: torch.Tensor, name: str) -> torch.Tensor:
     if t.dtype != torch.float32 or not t.is_cuda:
         raise hip.VarHipError(f'{name}: the MI355X sampling path needs fp32 CUDA parameters, got {t.dtype} on {t.device}')
@@ -67,7 +82,11 @@ class _VaeOps:
         self._gn_part = None            # (tensor, partial sums, blocks per sample) left by the last conv for the GroupNorm after it
 
     def _signature(self):
-        return tuple((p.data_ptr(), p._version) for p in self.vae.parameters())
+        return _signature(self.vae.parameters())
+
+    def invalidate(self):
+        """drop the packed weight copies: the next call re-reads the module's parameters"""
+        self._sig = None
 
     def _pack(self):
         """our copies of the weights this engine uses: 3x3 kernels re-laid [Cout][3][3][Cin] (Cin zero-padded to a multiple of 32),
@@ -239,16 +258,17 @@ class QuantizerEngine:
 
     def refresh(self):
         q = self.quant
-        sig = tuple((p.data_ptr(), p._version) for p in q.parameters())
+        sig = _signature(q.parameters())
         if sig == self._sig:
             return
-        if q.using_znorm:
-            raise NotImplementedError('using_znorm=True (cosine nearest-code) is not on the HIP path')
         self.codebook = _chk(q.embedding.weight.detach(), 'codebook')
         self.phi = [(_chk(p.weight.detach(), 'phi').permute(0, 2, 3, 1).contiguous(), _chk(p.bias.detach(), 'phi'), float(p.resi_ratio))
                     for p in q.quant_resi.phis()]
         self._taps = {}
         self._sig = sig
+
+    def invalidate(self):
+        self._sig = None
 
     def taps(self, pn, P, dev):
         if (pn, P) not in self._taps:
@@ -273,12 +293,39 @@ class QuantizerEngine:
             else:
                 z = f_rest
             idx = torch.empty(B * pn * pn, dtype=torch.int64, device=dev)
-            hip.call('nearest_code_f32', z, self.codebook, idx, B * pn * pn, self.codebook.shape[0], Cv)
+            # argmin |z - e|^2, or argmax cos(z, e) when using_znorm (quant.py:151-157)
+            hip.call('nearest_code_cos_f32' if self.quant.using_znorm else 'nearest_code_f32', z, self.codebook, idx, B * pn * pn, self.codebook.shape[0], Cv)
             ti, tw = self.taps(pn, P, dev) if pn != P else (None, None)
             pw, pb, ratio = self.phi[phi_index(si, S, len(self.phi))]
             hip.call('quant_residual_f32', idx, self.codebook, ti, tw, pw, pb, ratio, up, f_hat, f_rest, B, pn, P, Cv)
             out.append(f_hat.permute(0, 3, 1, 2).contiguous() if to_fhat else idx.view(B, pn * pn))
         return out
+
+    @torch.no_grad()
+    def fhat_from_scales(self, items, patch_nums, from_tokens: bool, last_one: bool):
+        """f_hat (B, Cvae, P, P) accumulated over all scales (quant.py:107-133 embed_to_fhat with all_to_max_scale=True; with
+        from_tokens=True the codebook lookup of vqvae.py:77-84 idxBl_to_img is fused in).  items[si]: (B, pn*pn) token ids, or the
+        embedding maps (B, Cvae, pn, pn).  Same kernels, same order of operations as the sampling loop's incremental f_hat."""
+        self.refresh()
+        B, P, Cv, S = items[0].shape[0], patch_nums[-1], self.codebook.shape[1], len(patch_nums)
+        dev = self.codebook.device
+        f_hat = torch.zeros((B, P, P, Cv), dtype=torch.float32, device=dev)
+        up = torch.empty_like(f_hat)
+        outs = []
+        for si, pn in enumerate(patch_nums):
+            ti, tw = self.taps(pn, P, dev) if pn != P else (None, None)
+            pw, pb, ratio = self.phi[phi_index(si, S, len(self.phi))]
+            if from_tokens:
+                hip.call('quant_accum_f32', items[si].to(dev, torch.int64).contiguous(), self.codebook, ti, tw, pw, pb, ratio, up, f_hat, B, pn, P, Cv)
+            else:
+                h = torch.empty((B, pn * pn, Cv), dtype=torch.float32, device=dev)
+                hip.call('nchw_to_nhwc_f32', items[si].to(dev, torch.float32).contiguous(), h, B, Cv, pn * pn)
+                hip.call('quant_accum_h_f32', h, ti, tw, pw, pb, ratio, up, f_hat, B, pn, P, Cv)
+            if not last_one or si == S - 1:
+                o = torch.empty((B, Cv, P, P), dtype=torch.float32, device=dev)
+                hip.call('nhwc_to_nchw_f32', f_hat, o, B, Cv, P * P)
+                outs.append(o)
+        return outs[-1] if last_one else outs
 
     @torch.no_grad()
     def var_input(self, idx_list, patch_nums) -> torch.Tensor:
@@ -363,9 +410,11 @@ class SamplingEngine:
     def refresh(self):
         var = self.var
         quant = var.vae_quant_proxy[0]
-        sig = tuple((p.data_ptr(), p._version) for p in list(var.parameters()) + list(quant.parameters()))
+        sig = _signature(list(var.parameters()) + list(quant.parameters()))
         if sig == self._sig:
             return
+        if var.C != 64 * var.num_heads:
+            raise hip.VarHipError(f'the HIP attention kernels are built for head_dim 64, got embed_dim {var.C} / {var.num_heads} heads')
         dev = var.pos_start.device
         w = {}
         g = lambda t, n: _chk(t.detach(), n)
@@ -406,6 +455,11 @@ class SamplingEngine:
                 w['taps'][pn] = (torch.from_numpy(ti).to(dev), torch.from_numpy(tw).to(dev))
         self.w = w
         self._sig = sig
+
+    def invalidate(self):
+        """forget the packed weight copies of the sampling loop and of the decoder (call after editing parameters through `.data`)"""
+        self._sig = None
+        self.dec.invalidate()
 
     # -- workspaces --------------------------------------------------------------------------------------------------
     def workspace(self, B: int):
@@ -491,8 +545,6 @@ class SamplingEngine:
         gt = keep_u8 = skip = masked = None
         draws = 0
         if more_smooth:
-            if gt_tokens is not None:
-                raise NotImplementedError('inpainting with more_smooth: the reference reads logits it did not compute on fully kept scales')
             lmax = max(p * p for p in var.patch_nums)
             if 'probs' not in ws:
                 ws['masked'] = torch.empty(B * lmax, V, dtype=torch.float32, device=dev)
@@ -508,6 +560,10 @@ class SamplingEngine:
             keep = keep_mask.to(dev).bool()
             keep_u8 = keep.to(torch.uint8).contiguous()
             skip = torch.stack([keep[:, b0:e0].all() for b0, e0 in var.begin_ends]).tolist()      # one host sync for all scales
+            if more_smooth and any(skip):
+                # var.py:312-341 (fork): on a fully kept scale the reference feeds the gumbel softmax the PREVIOUS scale's logits
+                # (a NameError on the first scale, a shape error afterwards) — there is no behaviour to reproduce
+                raise NotImplementedError('inpainting(more_smooth=True) with a fully kept scale: undefined in the reference (it reads logits it did not compute)')
 
         sm_gt = sm_ll = sm_dl = None
         if smooth is not None:

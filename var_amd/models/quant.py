@@ -111,7 +111,11 @@ class VectorQuantizer2(nn.Module):
         return self.quant_resi[si / (SN - 1)](h_BChw.contiguous())
 
     def embed_to_fhat(self, ms_h_BChw: List[torch.Tensor], all_to_max_scale=True, last_one=False):
-        """reference quant.py:107-133"""
+        """reference quant.py:107-133.  fp32 CUDA maps outside autograd run the HIP quantizer kernels (the same ones, in the same order,
+        as the sampling loop's incremental f_hat: identical bits); anything else the PyTorch code below."""
+        if (all_to_max_scale and len(ms_h_BChw) == len(self.v_patch_nums) and self._hip_eligible(ms_h_BChw[0])
+                and all(h.dtype == torch.float32 and h.shape[-1] == pn and h.shape[-2] == pn for h, pn in zip(ms_h_BChw, self.v_patch_nums))):
+            return self.hip_engine().fhat_from_scales(list(ms_h_BChw), tuple(self.v_patch_nums), from_tokens=False, last_one=last_one)
         B, SN = ms_h_BChw[0].shape[0], len(self.v_patch_nums)
         outs = []
         if all_to_max_scale:
@@ -137,8 +141,8 @@ class VectorQuantizer2(nn.Module):
 
     def _hip_eligible(self, t: torch.Tensor, v_patch_nums=None) -> bool:
         pns = v_patch_nums or self.v_patch_nums
-        return (t.is_cuda and not torch.is_grad_enabled() and not self.using_znorm and self.prog_si < 0
-                and self.embedding.weight.dtype == torch.float32 and all(isinstance(p, int) for p in pns))
+        return (t.is_cuda and not torch.is_grad_enabled() and self.prog_si < 0 and self.embedding.weight.is_cuda
+                and self.embedding.weight.dtype == torch.float32 and isinstance(self.quant_resi[0.0], Phi) and all(isinstance(p, int) for p in pns))
 
     def f_to_idxBl_or_fhat(self, f_BChw: torch.Tensor, to_fhat: bool, v_patch_nums: Optional[Sequence[Union[int, Tuple[int, int]]]] = None):
         """residual quantisation of an encoder feature map, scale by scale (reference quant.py:135-166)"""

@@ -108,8 +108,9 @@ class VAR(nn.Module):
 
     def forward(self, label_B: torch.LongTensor, x_BLCv_wo_first_l: torch.Tensor) -> torch.Tensor:
         """logits (B, L, V) for teacher-forced inputs (B, L-first_l, Cvae); block-causal mask instead of a KV cache"""
-        if (not torch.is_grad_enabled() and self.prog_si < 0 and self.lvl_1L.is_cuda and self.head.weight.dtype == torch.float32
-                and x_BLCv_wo_first_l is not None and x_BLCv_wo_first_l.shape[1] == self.L - self.first_l):
+        if (not torch.is_grad_enabled() and not self.training and self.prog_si < 0 and self.lvl_1L.is_cuda and self.head.weight.dtype == torch.float32
+                and self.C == 64 * self.num_heads and x_BLCv_wo_first_l is not None and x_BLCv_wo_first_l.shape[1] == self.L - self.first_l):
+            # (train mode keeps the PyTorch branch below: DropPath / dropout are live there, reference helpers.py:39-59)
             # inference (no autograd): scale-by-scale over the KV cache on the HIP kernels, fp32, same label dropping as below
             label_B = torch.where(torch.rand(label_B.shape[0], device=label_B.device) < self.cond_drop_rate, self.num_classes, label_B)
             return self.engine().teacher_forced_logits(label_B, x_BLCv_wo_first_l)
@@ -140,8 +141,6 @@ class VAR(nn.Module):
         Runs the same HIP loop as autoregressive_infer_cfg with the token replacement fused in (SamplingEngine.sample)."""
         if mask.shape != gt_tokens.shape:
             raise ValueError('Mask shape must match the latent token shape obtained from vae.img_to_idxBl')
-        if more_smooth:
-            raise NotImplementedError('more_smooth (gumbel) sampling is a "next" row of SURVEY.md §8(f)')
         dev = self.lvl_1L.device
         if dev.type != 'cuda':
             raise RuntimeError('VAR.inpainting: this build runs the sampling loop on MI355X HIP kernels only (no CPU fallback by design)')
@@ -152,7 +151,9 @@ class VAR(nn.Module):
             label = torch.full((B,), fill_value=label, device=dev)
         if g_seed is None: rng = None
         else: self.rng.manual_seed(g_seed); rng = self.rng
-        return self.engine().sample(B, label.to(dev).long(), rng, cfg, top_k, top_p, gt_tokens=gt_tokens, keep_mask=mask)
+        # more_smooth (var.py:332-341): the embeddings then come from the gumbel softmax of the filtered logits alone — the kept tokens
+        # only enter through the reference's `final_tokens`, which that branch never reads; defined only when no scale is fully kept
+        return self.engine().sample(B, label.to(dev).long(), rng, cfg, top_k, top_p, gt_tokens=gt_tokens, keep_mask=mask, more_smooth=bool(more_smooth))
 
     def smooth_sampling(self, gt_tokens: torch.Tensor, n: int, label: Optional[Union[int, torch.LongTensor]] = None,
                         g_seed: Optional[int] = None, cfg: float = 1.5, more_smooth: bool = False,
@@ -203,6 +204,17 @@ class VAR(nn.Module):
                 lin.weight.data[2 * self.C:].mul_(init_adaln); lin.weight.data[:2 * self.C].mul_(init_adaln_gamma); lin.bias.data.zero_()
             else:
                 blk.ada_gss.data[:, :, 2:].mul_(init_adaln); blk.ada_gss.data[:, :, :2].mul_(init_adaln_gamma)
+        self.invalidate_engine()           # `.data` edits bump no version counter: the HIP engine must re-read the weights
+
+    def invalidate_engine(self):
+        """Tell the HIP engine that parameters changed behind autograd's back (`p.data.copy_()`, EMA swaps, checkpoint surgery)."""
+        if self._engine is not None:
+            self._engine.invalidate()
+
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        ret = super().load_state_dict(state_dict, strict=strict, assign=assign)
+        self.invalidate_engine()
+        return ret
 
     def extra_repr(self):
         return f'drop_path_rate={self.drop_path_rate:g}'

@@ -82,6 +82,12 @@ class VQVAE(nn.Module):
         return self.quantize.f_to_idxBl_or_fhat(self.img_to_post(inp_img_no_grad), to_fhat=True, v_patch_nums=v_patch_nums)
 
     def idxBl_to_img(self, ms_idx_Bl: List[torch.Tensor], same_shape: bool, last_one=False):
+        q = self.quantize
+        if (same_shape and len(ms_idx_Bl) == len(q.v_patch_nums) and q._hip_eligible(ms_idx_Bl[0])
+                and all(i.shape[1] == pn * pn for i, pn in zip(ms_idx_Bl, q.v_patch_nums))):
+            # codebook lookup + bicubic + Phi + accumulate fused on HIP (what the sampling loop runs per scale), then the HIP decoder
+            f = q.hip_engine().fhat_from_scales(list(ms_idx_Bl), tuple(q.v_patch_nums), from_tokens=True, last_one=last_one)
+            return self.fhat_to_img(f) if last_one else [self.fhat_to_img(x) for x in f]
         B = ms_idx_Bl[0].shape[0]
         hs = []
         for idx_Bl in ms_idx_Bl:
@@ -101,4 +107,13 @@ class VQVAE(nn.Module):
         k = 'quantize.ema_vocab_hit_SV'        # checkpoints trained with another number of scales: keep ours (reference vqvae.py:100-103)
         if k in state_dict and state_dict[k].shape[0] != self.quantize.ema_vocab_hit_SV.shape[0]:
             state_dict[k] = self.quantize.ema_vocab_hit_SV
-        return super().load_state_dict(state_dict=state_dict, strict=strict, assign=assign)
+        ret = super().load_state_dict(state_dict=state_dict, strict=strict, assign=assign)
+        self.invalidate_engines()
+        return ret
+
+    def invalidate_engines(self):
+        """the HIP engines keep re-laid copies of the conv / Phi / codebook weights keyed on (address, version counter); edits through
+        `.data` bump no counter — call this after them (load_state_dict does)"""
+        for e in (self._hip_decoder, self._hip_encoder, getattr(self.quantize, '_hip_engine', None)):
+            if e is not None:
+                e.invalidate()
