@@ -16,8 +16,8 @@
 //     With it the K tile needs no reordering (it goes global -> LDS by LDS-DMA), Q is loaded straight into registers, and P feeds
 //     the second MFMA as the accumulator registers stand (C layout: half h, register 4g + j = key 8g + 4h + j): no lane exchange.
 //   Vector-ALU work is paid in matrix time next to fp32 MFMAs, so the softmax is written for instruction count:
-//   the exponential is vm_exp_le0 (include/var_math.h: clamp, one fma for n, integer exponent add) on register PAIRS with packed
-//   fp32 operations; the row sum is kept as four partial sums per query (one packed accumulator per lane half):
+//   the exponential is vm_exp_le0 (include/var_math.h: clamp, one fma for n, integer exponent add) in plain fp32 instructions;
+//   the row sum is kept as four partial sums per query (two accumulators per lane half):
 //       S[h][x] = sum over keys with ((key >> 2) & 1) == h and (key & 1) == x, ascending;   l = (S[0][0] + S[0][1]) + (S[1][0] + S[1][1])
 //   and the final normalisation is one reciprocal per query and a multiply per element.
 #include "common.h"
@@ -31,55 +31,51 @@
 __device__ __forceinline__ float vh_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float vh_clamp_m87(float x) { float r; asm("v_max_f32 %0, 0xc2ae0000, %1" : "=v"(r) : "v"(x)); return r; }
 
-// vm_exp_le0 (include/var_math.h) on four elements (two register pairs, packed fp32 operations): element for element the same
-// operations in the same order.  Written on 4-vectors so that the two pairs' dependent chains alternate in the instruction stream.
-__device__ __forceinline__ f32x4 vh_exp_le0_quad(f32x4 x) {
-    x[0] = vh_clamp_m87(x[0]); x[1] = vh_clamp_m87(x[1]); x[2] = vh_clamp_m87(x[2]); x[3] = vh_clamp_m87(x[3]);
-    const f32x4 t = __builtin_elementwise_fma(x, (f32x4)(1.44269504088896341f), (f32x4)(12582912.0f));
-    const f32x4 n = t - 12582912.0f;
-    f32x4 r = __builtin_elementwise_fma(n, (f32x4)(-0.693145751953125f), x);
-    r = __builtin_elementwise_fma(n, (f32x4)(-1.42860682030941723212e-6f), r);
-    f32x4 q = (f32x4)(1.9875691500e-4f);
-    q = __builtin_elementwise_fma(q, r, (f32x4)(1.3981999507e-3f));
-    q = __builtin_elementwise_fma(q, r, (f32x4)(8.3334519073e-3f));
-    q = __builtin_elementwise_fma(q, r, (f32x4)(4.1665795894e-2f));
-    q = __builtin_elementwise_fma(q, r, (f32x4)(1.6666665459e-1f));
-    q = __builtin_elementwise_fma(q, r, (f32x4)(5.0000001201e-1f));
-    const f32x4 y = __builtin_elementwise_fma(q, r * r, r) + 1.0f;
-    f32x4 o;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = __uint_as_float(__float_as_uint(y[i]) + (__float_as_uint(t[i]) << 23));
-    return o;
-}
 // one LDS-DMA request: 16 bytes per lane from base + voff to LDS address lds + 16 * lane (M0 written and clobbered in the statement)
 __device__ __forceinline__ void vh_attn_dma16(const void* base, uint32_t voff, uint32_t lds) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(base), "s"(lds) : "memory", "m0");
 }
 
-// vm_exp_le0 on one register pair (the dependent chain of one pair at a time: fewest live temporaries)
-__device__ __forceinline__ f32x2 vh_exp_le0_pair(f32x2 x) {
-    x[0] = vh_clamp_m87(x[0]); x[1] = vh_clamp_m87(x[1]);
-    const f32x2 t = __builtin_elementwise_fma(x, (f32x2)(1.44269504088896341f), (f32x2)(12582912.0f));
-    const f32x2 n = t - 12582912.0f;
-    f32x2 r = __builtin_elementwise_fma(n, (f32x2)(-0.693145751953125f), x);
-    r = __builtin_elementwise_fma(n, (f32x2)(-1.42860682030941723212e-6f), r);
-    f32x2 q = (f32x2)(1.9875691500e-4f);
-    q = __builtin_elementwise_fma(q, r, (f32x2)(1.3981999507e-3f));
-    q = __builtin_elementwise_fma(q, r, (f32x2)(8.3334519073e-3f));
-    q = __builtin_elementwise_fma(q, r, (f32x2)(4.1665795894e-2f));
-    q = __builtin_elementwise_fma(q, r, (f32x2)(1.6666665459e-1f));
-    q = __builtin_elementwise_fma(q, r, (f32x2)(5.0000001201e-1f));
-    const f32x2 y = __builtin_elementwise_fma(q, r * r, r) + 1.0f;
-    f32x2 o;
-    o[0] = __uint_as_float(__float_as_uint(y[0]) + (__float_as_uint(t[0]) << 23));
-    o[1] = __uint_as_float(__float_as_uint(y[1]) + (__float_as_uint(t[1]) << 23));
-    return o;
+// vm_exp_le0 (include/var_math.h) with plain fp32 instructions, on four independent elements whose chains alternate: element for
+// element the same operations in the same order.  Next to fp32 MFMAs a packed fp32 instruction (v_pk_fma_f32 ...) costs the matrix
+// pipe about three plain ones (fitted from three builds of this kernel), so the unpacked form wins although it is
+// twice the instruction count.  (attn.hip is compiled with -fno-slp-vectorize: the compiler would re-pack adjacent operations.)
+__device__ __forceinline__ void vh_exp_le0_x4(float& a, float& b, float& c, float& d) {
+    float x[4] = {vh_clamp_m87(a), vh_clamp_m87(b), vh_clamp_m87(c), vh_clamp_m87(d)}, t[4], r[4], q[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = __builtin_fmaf(x[i], 1.44269504088896341f, 12582912.0f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const float n = t[i] - 12582912.0f; r[i] = __builtin_fmaf(n, -0.693145751953125f, x[i]); r[i] = __builtin_fmaf(n, -1.42860682030941723212e-6f, r[i]); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = __builtin_fmaf(1.9875691500e-4f, r[i], 1.3981999507e-3f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = __builtin_fmaf(q[i], r[i], 8.3334519073e-3f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = __builtin_fmaf(q[i], r[i], 4.1665795894e-2f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = __builtin_fmaf(q[i], r[i], 1.6666665459e-1f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = __builtin_fmaf(q[i], r[i], 5.0000001201e-1f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const float y = __builtin_fmaf(q[i], r[i] * r[i], r[i]) + 1.0f; x[i] = __uint_as_float(__float_as_uint(y) + (__float_as_uint(t[i]) << 23)); }
+    a = x[0]; b = x[1]; c = x[2]; d = x[3];
 }
 
-// WPS: waves per SIMD the register allocation is capped for (NW == 4: 4 -> 128 registers, the exponentials one pair at a time;
-// 3 -> 168 registers, two pairs' chains alternating)
-template <int NW, int WPS>
-__global__ void __launch_bounds__(NW * 64, WPS) k_attn_cached(const float* __restrict__ q, const float* __restrict__ kcache, const float* __restrict__ vcache,
+__device__ __forceinline__ float vh_exp_le0_s(float x) {
+    x = vh_clamp_m87(x);
+    const float t = __builtin_fmaf(x, 1.44269504088896341f, 12582912.0f), n = t - 12582912.0f;
+    float r = __builtin_fmaf(n, -0.693145751953125f, x);
+    r = __builtin_fmaf(n, -1.42860682030941723212e-6f, r);
+    float q = __builtin_fmaf(1.9875691500e-4f, r, 1.3981999507e-3f);
+    q = __builtin_fmaf(q, r, 8.3334519073e-3f); q = __builtin_fmaf(q, r, 4.1665795894e-2f);
+    q = __builtin_fmaf(q, r, 1.6666665459e-1f); q = __builtin_fmaf(q, r, 5.0000001201e-1f);
+    const float y = __builtin_fmaf(q, r * r, r) + 1.0f;
+    return __uint_as_float(__float_as_uint(y) + (__float_as_uint(t) << 23));
+}
+
+// NW waves per workgroup; the register allocation is capped for 4 workgroups per CU (NW waves per SIMD: 128 registers at NW = 4)
+template <int NW>
+__global__ void __launch_bounds__(NW * 64, NW) k_attn_cached(const float* __restrict__ q, const float* __restrict__ kcache, const float* __restrict__ vcache,
                                                               float* __restrict__ out, int l, int H, int curL, int Lmax) {
     constexpr int NT = NW * 64, NIT = (256 + NT - 1) / NT;       // V staging items (key row, 8-float chunk) per thread and tile
     constexpr int KST = 8 * KPIECE;                               // floats per K stage
@@ -197,27 +193,19 @@ __global__ void __launch_bounds__(NW * 64, WPS) k_attn_cached(const float* __res
                 auto xr = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
                 const float mnew = vh_max3(mx, __uint_as_float(xr[0]), __uint_as_float(xr[1]));
                 if (__any(mnew != mx)) {
-                    const f32x2 d2 = {mx - mnew, mx - mnew};                       // (first tile: m = -inf, O = l = 0)
-                    const float alpha = vh_exp_le0_quad(f32x4{d2[0], d2[1], d2[0], d2[1]})[0];
-                    lsum = lsum * alpha;
+                    const float alpha = vh_exp_le0_s(mx - mnew);                   // (first tile: m = -inf, O = l = 0)
+                    lsum[0] = lsum[0] * alpha; lsum[1] = lsum[1] * alpha;
 #pragma unroll
                     for (int e = 0; e < 16; ++e) { o0[e] = o0[e] * alpha; o1[e] = o1[e] * alpha; }
                 }
                 mx = mnew;
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (NW == 4 && WPS == 4) {
-                // one pair's chain at a time: anything wider does not fit 128 registers (the Q fragments get spilled)
-#define VH_EXP2(E) { const f32x2 pe = vh_exp_le0_pair(f32x2{p[E], p[E + 1]} - mx); p[E] = pe[0]; p[E + 1] = pe[1]; __builtin_amdgcn_sched_barrier(0); }
-                VH_EXP2(0) VH_EXP2(2) VH_EXP2(4) VH_EXP2(6) VH_EXP2(8) VH_EXP2(10) VH_EXP2(12) VH_EXP2(14)
-#undef VH_EXP2
-            } else {
-                // two pairs' chains alternating: covers the dependent-issue wait states of the packed operations
-#define VH_EXP4(E) { const f32x4 pe = vh_exp_le0_quad(f32x4{p[E], p[E + 1], p[E + 2], p[E + 3]} - mx); \
-                     p[E] = pe[0]; p[E + 1] = pe[1]; p[E + 2] = pe[2]; p[E + 3] = pe[3]; __builtin_amdgcn_sched_barrier(0); }
-                VH_EXP4(0) VH_EXP4(4) VH_EXP4(8) VH_EXP4(12)
-#undef VH_EXP4
-            }
+            // four elements at a time: with all sixteen chains interleaved the temporaries do not fit 128 registers (the Q fragments get spilled)
+#define VH_EXP4S(E) { float a_ = p[E] - mx, b_ = p[E + 1] - mx, c_ = p[E + 2] - mx, d_ = p[E + 3] - mx; vh_exp_le0_x4(a_, b_, c_, d_); \
+                      p[E] = a_; p[E + 1] = b_; p[E + 2] = c_; p[E + 3] = d_; __builtin_amdgcn_sched_barrier(0); }
+            VH_EXP4S(0) VH_EXP4S(4) VH_EXP4S(8) VH_EXP4S(12)
+#undef VH_EXP4S
             if (ragged) {                                          // keys past curL do not exist: no share of the row sum
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
@@ -230,8 +218,8 @@ __global__ void __launch_bounds__(NW * 64, WPS) k_attn_cached(const float* __res
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 v0 = *(const f32x4*)(vb + g * 8), v1 = *(const f32x4*)(vb + 32 * VLD + g * 8);   // channels r and r+32, keys 8g + 4h ..
-                lsum = lsum + f32x2{p[4 * g], p[4 * g + 1]};           // accumulator [x]: keys with (key & 1) == x of this half, ascending
-                lsum = lsum + f32x2{p[4 * g + 2], p[4 * g + 3]};
+                lsum[0] = lsum[0] + p[4 * g]; lsum[1] = lsum[1] + p[4 * g + 1];         // accumulator [x]: keys with (key & 1) == x of this half, ascending
+                lsum[0] = lsum[0] + p[4 * g + 2]; lsum[1] = lsum[1] + p[4 * g + 3];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[j], p[4 * g + j], o0, 0, 0, 0);
@@ -285,18 +273,16 @@ extern "C" int varhip_attn_cached_f32(const float* q, const float* kcache, const
     VhScope sc(VH_FAM_ATTN, (hipStream_t)stream, 4.0 * B2 * H * (double)l * curL * 64,
                4.0 * B2 * H * (2.0 * curL * 64 + 2.0 * l * 64));
     static const int forced = [] { const char* e = getenv("VARHIP_ATTN_WAVES"); return e ? atoi(e) : 0; }();   // experiments only
-    static const int wps3 = [] { const char* e = getenv("VARHIP_ATTN_WPS3"); return e ? atoi(e) : 0; }();       // experiments only
     const int nw = (forced >= 1 && forced <= 4) ? forced : attn_waves(l);
     dim3 grid((l + nw * 32 - 1) / (nw * 32), H, B2);
     hipStream_t s = (hipStream_t)stream;
     switch (nw) {
-        case 1: hipLaunchKernelGGL((k_attn_cached<1, 1>), grid, dim3(64), 0, s, q, kcache, vcache, out, l, H, curL, Lmax); break;
-        case 2: hipLaunchKernelGGL((k_attn_cached<2, 2>), grid, dim3(128), 0, s, q, kcache, vcache, out, l, H, curL, Lmax); break;
-        case 3: hipLaunchKernelGGL((k_attn_cached<3, 3>), grid, dim3(192), 0, s, q, kcache, vcache, out, l, H, curL, Lmax); break;
-        default:
-            if (wps3) hipLaunchKernelGGL((k_attn_cached<4, 3>), grid, dim3(256), 0, s, q, kcache, vcache, out, l, H, curL, Lmax);
-            else hipLaunchKernelGGL((k_attn_cached<4, 4>), grid, dim3(256), 0, s, q, kcache, vcache, out, l, H, curL, Lmax);
-            break;
+#define VH_ATTN_LAUNCH(NW_) hipLaunchKernelGGL((k_attn_cached<NW_>), grid, dim3(NW_ * 64), 0, s, q, kcache, vcache, out, l, H, curL, Lmax)
+        case 1: VH_ATTN_LAUNCH(1); break;
+        case 2: VH_ATTN_LAUNCH(2); break;
+        case 3: VH_ATTN_LAUNCH(3); break;
+        default: VH_ATTN_LAUNCH(4); break;
+#undef VH_ATTN_LAUNCH
     }
     return vh_launch_status();
 }

@@ -403,14 +403,14 @@ class SamplingEngine:
         self.var = var
         self._sig = None
         self._ws: Dict[int, dict] = {}
-        self.dec = DecoderEngine(var.vae_proxy[0])
+        self.dec = var.vae_proxy[0]._decoder_engine()       # the VQVAE's own engine: one packed copy of the decoder weights, one place to invalidate
         self.last_trace: Optional[dict] = None
 
     # -- weights -----------------------------------------------------------------------------------------------------
     def refresh(self):
         var = self.var
         quant = var.vae_quant_proxy[0]
-        sig = _signature(list(var.parameters()) + list(quant.parameters()))
+        sig = _signature(list(var.parameters()) + list(quant.parameters())) + (getattr(var.vae_proxy[0], '_hip_generation', 0),)
         if sig == self._sig:
             return
         if var.C != 64 * var.num_heads:

@@ -31,6 +31,7 @@ class VQVAE(nn.Module):
         self.post_quant_conv = nn.Conv2d(self.Cvae, self.Cvae, quant_conv_ks, stride=1, padding=quant_conv_ks // 2)
         self._hip_decoder = None
         self._hip_encoder = None
+        self._hip_generation = 0            # bumped by invalidate_engines(); part of the sampling engine's weight signature
         if self.test_mode:
             self.eval()
             for p in self.parameters(): p.requires_grad_(False)
@@ -114,6 +115,7 @@ class VQVAE(nn.Module):
     def invalidate_engines(self):
         """the HIP engines keep re-laid copies of the conv / Phi / codebook weights keyed on (address, version counter); edits through
         `.data` bump no counter — call this after them (load_state_dict does)"""
+        self._hip_generation += 1
         for e in (self._hip_decoder, self._hip_encoder, getattr(self.quantize, '_hip_engine', None)):
             if e is not None:
                 e.invalidate()
