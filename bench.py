@@ -3,12 +3,20 @@
 
 One "step" = one VAR.autoregressive_infer_cfg-equivalent call: the whole 10-scale sampling loop + VQVAE decode for
 B=64 images per GPU (BASELINE.json configs[1]), random-init weights (var_amd.detinit, seed 0), labels (i*7) mod 1000.
-N>1 (torchrun, one rank per GPU over RCCL): the batch is sharded image-wise, no collective inside the loop, one all-gather of
-the decoded images inside the timed region (var_amd/multi.py).  `value` = images of all ranks / max-over-ranks time.
+N>1: one rank per GPU over RCCL — under torchrun, or started by this script itself when `--gpus N` is given outside a torchrun
+environment (var_amd/launch.py; the parent never touches a GPU).  The batch is sharded image-wise, no collective inside the loop,
+one all-gather of the decoded images inside the timed region (var_amd/multi.py).  `value` = images of all ranks / max-over-ranks time.
+
+--dtype f32 (default, the driver's line): the parity mode — token ids bit-identical to the CPU oracle, priced against the 157.3 TF
+fp32 MFMA peak.  --dtype f16: the 16-bit throughput mode of the transformer (fp16 GEMM operands / KV cache, fp32 accumulation; what the
+reference's harness requests with torch.autocast(fp16), demo_sample.py:66-68), priced against the 2.5 PF dense fp16 MFMA peak.
 
 Extra objects in the JSON line:
-  roofline     the dominant kernel family (by device time) of the timed region, measured with HIP events on the launch
-               stream by the library's timing table (include/var_hip.h): algorithmic FLOPs / time vs the fp32 MFMA peak.
+  roofline     the dominant kernel (largest device time among the single-symbol families, measured in the last warmup step with
+               every family timed), re-timed alone with HIP events on the launch stream over the timed region: algorithmic FLOPs / time.
+  whole_path   FLOPs per image as the reference computes them and as the kernels execute them (the decoder's Upsample2x convs run
+               in a folded 4-tap form), both as a fraction of the MFMA peak of the mode; mfma_time_weighted: FLOPs / time summed over
+               every GEMM / conv / attention launch of the profiled warmup step.
   cpu_baseline the CPU oracle (oracle/, a scalar C port of the reference algorithm; kind "port") timed on this box's host
                cores on a bounded sample: four images through all 10 scales + decode (rank 0, N=1 only).
 """
@@ -24,8 +32,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4, 64 FLOP/clk/SIMD
+PEAK_F16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense BF16/FP16 MFMA
 PEAK_HBM_GBS = 8000.0
+MFMA_FAMILIES = ('gemm', 'gemm_small', 'conv3x3', 'conv_small', 'attn')
 
 
 def main():
@@ -35,10 +45,11 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--batch', type=int, default=64, help='images per GPU (weak scaling)')
     ap.add_argument('--depth', type=int, default=16)
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'f16'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--rng-mode', default='exact', choices=['exact', 'per_rank'])
     ap.add_argument('--kernel-breakdown', action='store_true',
-                    help='time every kernel family with HIP events (adds ~2 %% to a step); default: only the dominant kernel of the roofline object')
+                    help='time every kernel family with HIP events in the timed region too (adds ~2 %% to a step); default: only the dominant kernel')
     args = ap.parse_args()
 
     # `python bench.py --gpus N` outside a torchrun environment: start the N ranks ourselves.  Nothing above or below this point in
@@ -68,6 +79,7 @@ def main():
     fill_module_(var, args.depth, 0, 'var.'); fill_module_(vae, args.depth, 0, 'vae.')
     var.eval(); vae.eval()
     var.rng = torch.Generator(device=dev)
+    var.set_hip_precision(args.dtype)
 
     B_local, B_total = args.batch, args.batch * world
     labels = ((torch.arange(B_total) * 7) % 1000).to(dev)
@@ -75,13 +87,18 @@ def main():
     def step(i):
         return sample_sharded(var, B_total, labels, g_seed=i, cfg=1.5, top_k=900, top_p=0.96, rng_mode=args.rng_mode, gather=True)
 
+    # warmup; the last warmup step runs with every family timed: it names the dominant kernel and gives the per-family table
+    prepass = None
     for i in range(args.warmup):
+        last = i == args.warmup - 1
+        if last: hip.timing_reset(); hip.timing_enable(True, None)
         step(i)
-    # HIP events around the launches, on the launch stream: every family with --kernel-breakdown, else only the dominant kernel.
-    # profiles/r01_bench_kernel_stats.csv: at d16 the decoder's 128x160 implicit-GEMM conv instantiation leads (33 % of the device
-    # time; the transformer GEMMs are spread over four tile instantiations of the same kernel, the largest at 21 %); at d30 (measured: 28 %)
-    # the 128x128 transformer GEMM instantiation leads; depths in between are assumed to follow d30.
-    dominant = 'conv3x3' if args.depth <= 16 else 'gemm'
+        if last:
+            torch.cuda.synchronize(); hip.timing_enable(False); prepass = hip.timing_read()
+    if prepass is not None:
+        dominant = max(('gemm', 'conv3x3', 'attn'), key=lambda k: prepass[k]['ms'])       # the families that map to one kernel symbol each
+    else:
+        dominant = 'conv3x3' if (args.depth <= 16 and args.dtype == 'f32') else 'gemm'    # (--warmup 0: r01/r02 profiles)
     hip.timing_reset(); hip.timing_enable(True, None if args.kernel_breakdown else [dominant])
     dist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -98,29 +115,54 @@ def main():
         dt = float(t.item())
 
     if rank == 0:
+        f16 = args.dtype == 'f16'
         ips = B_total * args.steps / dt
-        flops_img = var.engine().flops_per_image()
-        dec_flops_img = var.engine().dec.flops_per_image_reference(pns[-1])          # as the reference computes the decoder (9-tap upsample convs)
-        # dominant kernel by device time: with the full breakdown the measured leader among the single-symbol families is picked
-        fam = max(('gemm', 'conv3x3', 'attn'), key=lambda k: tt[k]['ms']) if args.kernel_breakdown else dominant
-        f = tt[fam]
+        eng = var.engine()
+        flops_img = eng.flops_per_image()
+        dec_ref = eng.dec.flops_per_image_reference(pns[-1])        # as the reference computes the decoder (9-tap upsample convs)
+        dec_exec = eng.dec.flops_per_image_executed(pns[-1])        # as the kernels execute it (folded 4-tap upsample convs)
+        # the decoder stays fp32 in both modes, so the f16 mode is priced per family: transformer families against the f16 peak
+        fam_peak = {k: (PEAK_F16_MFMA_TFLOPS if (f16 and k in ('gemm', 'gemm_small', 'attn')) else PEAK_F32_MFMA_TFLOPS) for k in MFMA_FAMILIES}
+        f = tt[dominant]
         achieved = f['flops'] / (f['ms'] * 1e-3) / 1e12 if f['ms'] > 0 else 0.0
-        kname = {'gemm': 'k_dma_gemm<4,4,false,2,false>', 'conv3x3': 'k_dma_gemm<4,5,true,2,false>', 'attn': 'k_attn_cached'}[fam]
-        traffic = None                                                       # HBM-side bytes per launch from a separate rocprofv3 --pmc pass
-        try:
-            pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))['kernels'].get(kname)
-            if pm and args.batch == 64 and args.depth == 16: traffic = pm['traffic_bytes_per_launch']
-        except (OSError, KeyError, ValueError):
-            pass
+        kname = {('gemm', False): 'k_dma_gemm<4,4,false,2,false>', ('conv3x3', False): 'k_dma_gemm<4,5,true,2,false>', ('attn', False): 'k_attn_cached<4>',
+                 ('gemm', True): 'k_gemm16<4,4>', ('conv3x3', True): 'k_dma_gemm<4,5,true,2,false>', ('attn', True): 'k_attn16<4>'}[(dominant, f16)]
+        peak = fam_peak[dominant]
+        traffic, tsrc = None, None                                   # HBM-side bytes per launch from a separate rocprofv3 --pmc pass of the same config
+        for prof in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+            try:
+                pj = json.load(open(os.path.join(ROOT, 'profiles', prof)))
+                pm = pj['kernels'].get(kname)
+                if pm and args.batch == 64 and args.depth == 16 and pj.get('dtype', 'f32') == args.dtype:
+                    traffic, tsrc = pm['traffic_bytes_per_launch'], f'profiles/{prof} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)'
+                    break
+            except (OSError, KeyError, ValueError):
+                pass
+        whole_peak = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS
+        whole = {'gflop_per_image_reference': round((flops_img + dec_ref) / 1e9, 1), 'gflop_per_image_executed': round((flops_img + dec_exec) / 1e9, 1),
+                 'tflops_reference': round(ips * (flops_img + dec_ref) / 1e12 / world, 2), 'tflops_executed': round(ips * (flops_img + dec_exec) / 1e12 / world, 2),
+                 'frac_of_mfma_peak_reference_flops': round(ips * (flops_img + dec_ref) / 1e12 / world / whole_peak, 4),
+                 'frac_of_mfma_peak_executed_flops': round(ips * (flops_img + dec_exec) / 1e12 / world / whole_peak, 4),
+                 'peak_tflops': whole_peak,
+                 'note': 'ada_lin counted once per call (hoisted; the reference recomputes it per scale); decoder stays fp32 in the f16 mode'}
+        table = tt if args.kernel_breakdown else prepass
+        if table is not None:
+            ms = sum(table[k]['ms'] for k in MFMA_FAMILIES); fl = sum(table[k]['flops'] for k in MFMA_FAMILIES)
+            ideal_ms = sum(table[k]['flops'] / (fam_peak[k] * 1e9) for k in MFMA_FAMILIES)
+            whole['mfma_time_weighted'] = {'tflops': round(fl / (ms * 1e-3) / 1e12, 2) if ms > 0 else None,
+                                           'frac_of_peak': round(ideal_ms / ms, 4) if ms > 0 else None,
+                                           'device_ms_per_step': round(ms / (args.steps if args.kernel_breakdown else 1), 3),
+                                           'source': 'timed region' if args.kernel_breakdown else 'last warmup step (every family timed)'}
         out = {
             'metric': '256x256 images/sec (CFG=1.5) VAR-d%d' % args.depth, 'value': round(ips, 3), 'unit': 'images/sec', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'VAR-d{args.depth} 256x256 full 10-scale pyramid, CFG=1.5, top_k=900, top_p=0.96, batch={B_local}/GPU, random-init (detinit seed 0)',
-                       'global_batch': B_total, 'parallelism': f'dp{world} (batch shard, RCCL all-gather of decoded images)', 'rng_mode': args.rng_mode},
-            'roofline': {'bound': 'mfma', 'kernel': kname,
-                         'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                         'traffic': traffic, 'traffic_source': 'profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)' if traffic else None,
+                       'global_batch': B_total, 'parallelism': f'dp{world} (batch shard, RCCL all-gather of decoded images)', 'rng_mode': args.rng_mode,
+                       'precision': 'fp32 parity mode' if not f16 else 'fp16 transformer operands / KV cache, fp32 accumulate; fp32 decoder'},
+            'roofline': {'bound': 'mfma', 'kernel': kname, 'dominant_by': 'measured (last warmup step)' if prepass is not None else 'profile',
+                         'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
+                         'traffic': traffic, 'traffic_source': tsrc,
                          'launches': f['launches'], 'avg_launch_ms': round(f['ms'] / max(f['launches'], 1), 5),
                          'algorithmic_gflop_per_launch': round(f['flops'] / max(f['launches'], 1) / 1e9, 3),
                          'algorithmic_mbytes_per_launch': round(f['bytes'] / max(f['launches'], 1) / 1e6, 3)},
@@ -128,10 +170,10 @@ def main():
             'kernel_tflops': {k: round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2) for k, v in tt.items() if v['ms'] > 0 and v['flops'] > 0},
             'kernel_algorithmic_gbps': {k: round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1) for k, v in tt.items() if v['ms'] > 0 and v['bytes'] > 0},
             'peak_hbm_allocated_gib': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
-            'whole_path': {'gflop_per_image': round((flops_img + dec_flops_img) / 1e9, 1),
-                           'tflops': round(ips * (flops_img + dec_flops_img) / 1e12 / world, 2),
-                           'frac_of_f32_mfma_peak': round(ips * (flops_img + dec_flops_img) / 1e12 / world / PEAK_F32_MFMA_TFLOPS, 4)},
+            'whole_path': whole,
         }
+        if prepass is not None:
+            out['warmup_step_kernel_ms'] = {k: round(v['ms'], 3) for k, v in prepass.items() if v['launches'] > 0}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.depth, pns)
         print(json.dumps(out), flush=True)

@@ -257,6 +257,38 @@ int varhip_nearest_code_f32(const float* z, const float* codebook, int64_t* idx_
  * first index on ties; every element is divided by its vector's norm before the (c-ascending fma) dot product, as F.normalize does */
 int varhip_nearest_code_cos_f32(const float* z, const float* codebook, int64_t* idx_out, int N, int V, int Cv, varhip_stream_t stream);
 
+/* ==== 16-bit-input throughput mode ("f16") ===================================================================
+ * The reference's harness runs the path under torch.autocast('cuda', dtype=torch.float16) (demo_sample.py:66-68): every F.linear of
+ * basic_var.py then computes in fp16 and attention takes the flash path with fp16 q/k/v (basic_var.py:97,113).  These entry points are
+ * that mode on MI355X: fp16 operands (`void*` = _Float16 data), fp32 accumulation on v_mfma_f32_*_f16, fp32 bias / GELU / AdaLN gate /
+ * residual, one rounding where an output is fp16.  They are NOT under the fp32 bit-exactness contract (the MFMA-internal reduction over
+ * k is not a k-ascending chain): tests compare them with the CPU twin (oracle/var_oracle.py, f16=True: the fp32 restatement with the same
+ * rounding points) within a stated tolerance.  LayerNorm, GroupNorm, softmax statistics, the sampler and the quantizer stay fp32. */
+
+/* out[m][n] = epi(sum_k A[m][k] W[n][k] + bias[n]); A: [M][lda] fp16, W: [N][ldw] fp16, bias / gamma fp32, out and resid fp16 or fp32
+ * (out_f16 / resid_f16).  epi as varhip_gemm_nt_f32.  Requires K % 64 == 0, N % 4 == 0, lda/ldw % 8 == 0, 16-byte aligned pointers.
+ * replaces F.linear at basic_var.py:93,119,52 and var.py:124 under fp16 autocast. */
+int varhip_gemm_nt_f16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                       void* out, int64_t ldo, int out_f16, int M, int N, int K, int epi,
+                       const void* resid, int64_t ldr, int resid_f16, const float* gamma, int64_t ldg, int rows_per_group,
+                       int batch, int64_t sA, int64_t sW, int64_t sO, varhip_stream_t stream);
+/* mat_qkv + q/k L2-norm + scale + KV-cache append (basic_var.py:93-109): fp16 x fp16 -> fp32 -> fp16 q [M][C] and fp16 caches [B2][H][Lmax][64] */
+int varhip_gemm_qkv_f16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, int M, int C, int K,
+                        const float* scale_mul, float plain_scale, int l2norm,
+                        void* q_out, void* kcache, void* vcache, int B2, int l, int H, int pos0, int Lmax, varhip_stream_t stream);
+/* attention over the fp16 KV cache (basic_var.py:107-117 on the flash path): fp32 scores and softmax, p rounded to fp16 for p.v, fp16 out */
+int varhip_attn_cached_f16(const void* q, const void* kcache, const void* vcache, void* out,
+                           int B2, int l, int H, int curL, int Lmax, varhip_stream_t stream);
+/* varhip_ln_modulate_f32 with the result rounded to fp16 (the A operand of the next GEMM) */
+int varhip_ln_modulate_f16out(const float* x, const float* scale, int64_t ld_scale, const float* shift, int64_t ld_shift,
+                              void* out, int M, int C, int rows_per_group, float eps, varhip_stream_t stream);
+/* one AdaLNSelfAttn block (basic_var.py:152-159) in this mode: fp32 residual stream and AdaLN parameters, fp16 GEMM operands and KV cache */
+int varhip_adaln_block_f16(float* x, float* x2, void* xn16, void* q16, void* att16, void* hid16, const float* ada, int64_t ld_ada,
+                           const void* qkv_w16, const float* qkv_b, const float* scale_mul, float plain_scale, int l2norm,
+                           const void* proj_w16, const float* proj_b, const void* fc1_w16, const float* fc1_b,
+                           const void* fc2_w16, const float* fc2_b, void* kcache16, void* vcache16,
+                           int B2, int l, int C, int H, int hidden, int pos0, int Lmax, float eps, varhip_stream_t stream);
+
 /* ---- per-kernel timing (bench.py's roofline leg) -----------------------------------------------------------
  * When enabled, every launch is bracketed by hipEvents on its own stream and its algorithmic FLOPs and bytes are
  * accumulated per kernel family.  varhip_timing_read synchronises the recorded events.

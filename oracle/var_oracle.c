@@ -297,6 +297,55 @@ int varref_attn_cached_f32(const float* q, const float* kcache, const float* vca
     return 0;
 }
 
+/* Twin of varhip_attn_cached_f16 (the 16-bit throughput mode, include/var_hip.h): q, k, v hold fp16-representable values; scores, the
+ * running maximum, p = exp(s - m) and the row sum are fp32; p is rounded to fp16 (round-to-nearest-even) for the p.v product only.
+ * Plain ascending orders: this mode is compared with a tolerance, not bit for bit. */
+#include <immintrin.h>
+static inline float round_f16(float x) { return _cvtsh_ss(_cvtss_sh(x, _MM_FROUND_TO_NEAREST_INT)); }
+int varref_attn_cached_p16_f32(const float* q, const float* kcache, const float* vcache, float* out,
+                               int B2, int l, int H, int curL, int Lmax) {
+    if (curL <= 0 || curL > Lmax) return VARHIP_EINVAL;
+    const int C = H * 64;
+#pragma omp parallel for collapse(2) schedule(dynamic, 4)
+    for (int b = 0; b < B2; ++b) {
+        for (int h = 0; h < H; ++h) {
+            const float* K = kcache + ((int64_t)b * H + h) * Lmax * 64;
+            const float* Vv = vcache + ((int64_t)b * H + h) * Lmax * 64;
+            for (int t = 0; t < l; ++t) {
+                const float* qr = q + ((int64_t)b * l + t) * C + h * 64;
+                float m = -INFINITY, ls = 0.0f;
+                float acc[64], s[32];
+                for (int c = 0; c < 64; ++c) acc[c] = 0.0f;
+                for (int j0 = 0; j0 < curL; j0 += 32) {
+                    const int nj = curL - j0 < 32 ? curL - j0 : 32;
+                    float tmax = -INFINITY;
+                    for (int jj = 0; jj < nj; ++jj) {
+                        float a = 0.0f;
+                        for (int d = 0; d < 64; ++d) a = vm_fma(K[(int64_t)(j0 + jj) * 64 + d], qr[d], a);
+                        s[jj] = a; tmax = vm_max(tmax, a);
+                    }
+                    const float mnew = vm_max(m, tmax);
+                    const float alpha = vm_exp(m - mnew);
+                    m = mnew;
+                    ls = ls * alpha;
+                    for (int c = 0; c < 64; ++c) acc[c] = acc[c] * alpha;
+                    for (int jj = 0; jj < nj; ++jj) {
+                        const float pj = vm_exp(s[jj] - m);
+                        ls = ls + pj;
+                        const float p16 = round_f16(pj);
+                        const float* vr = Vv + (int64_t)(j0 + jj) * 64;
+#pragma omp simd
+                        for (int c = 0; c < 64; ++c) acc[c] = vm_fma(p16, vr[c], acc[c]);
+                    }
+                }
+                float* o = out + ((int64_t)b * l + t) * C + h * 64;
+                for (int c = 0; c < 64; ++c) o[c] = round_f16(acc[c] / ls);
+            }
+        }
+    }
+    return 0;
+}
+
 /* CFG (var.py:172-173) + sample_with_top_k_top_p_ (helpers.py:6-19) + torch.multinomial(n=1) == argmax(p / Exp(1) noise) */
 typedef struct { uint32_t key; int32_t idx; } sortent_t;
 static int cmp_sortent(const void* a, const void* b) {

@@ -1,0 +1,195 @@
+"""The 16-bit throughput mode (include/var_hip.h "f16": fp16 GEMM operands / KV cache, fp32 accumulation on the f16 MFMAs) on a real MI355X.
+
+This mode is NOT under the fp32 bit-exactness contract: the MFMA-internal reduction over k is not a k-ascending fma chain.  It is tested
+  (a) kernel by kernel against float64 arithmetic on the same fp16 inputs (tolerances: fp32 accumulation noise, one fp16 rounding of outputs);
+  (b) end to end against its CPU twin (oracle.var_oracle.OracleVAR(f16=True): the fp32 restatement with the same rounding points), teacher-forced
+      with the reference's tokens so that a flipped token cannot cascade;
+  (c) against the reference's own fp32 run (golden fixtures): logits within a stated tolerance, token agreement reported as a rate.
+"""
+import contextlib
+import io
+import json
+
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+
+
+def _hip():
+    from var_amd import hip
+    return hip
+
+
+@pytest.mark.parametrize('M,N,K', [(128, 1024, 1024), (1152, 4096, 1024), (200, 1024, 4096), (50, 256, 64), (4096, 3072, 1024), (33, 132, 128)])
+@pytest.mark.parametrize('mode', ['none32', 'none16', 'gelu16', 'resid32', 'resid16in'])
+def test_gemm16_against_float64(M, N, K, mode):
+    hip = _hip()
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    A = (torch.randn(M, K, generator=g) * 0.7).half(); W = (torch.randn(N, K, generator=g) * (1.5 / K ** 0.5)).half()
+    bias = torch.randn(N, generator=g) * 0.2
+    rpg = 50 if M % 50 == 0 else M
+    gamma = torch.randn((M + rpg - 1) // rpg, N, generator=g) * 0.5
+    resid32 = torch.randn(M, N, generator=g)
+    ref = A.double() @ W.double().T + bias.double()
+    mag = (A.double().abs() @ W.double().abs().T)            # sum |a||w|: the scale of the fp32 accumulation noise
+    out16 = mode in ('none16', 'gelu16')
+    epi, resid, rf16, gm = 0, None, 0, None
+    if mode == 'gelu16':
+        epi = 1; ref = torch.nn.functional.gelu(ref, approximate='tanh')
+    elif mode == 'resid32':
+        epi = 2; resid = resid32.cuda(); gm = gamma.cuda()
+        ref = resid32.double() + ref * gamma.double().repeat_interleave(rpg, dim=0)[:M]
+    elif mode == 'resid16in':
+        epi = 2; resid = resid32.half().cuda(); rf16 = 1
+        ref = resid32.half().double() + ref
+    out = torch.empty(M, N, dtype=torch.float16 if out16 else torch.float32, device='cuda')
+    hip.call('gemm_nt_f16', A.cuda(), K, W.cuda(), K, bias.cuda(), out, N, int(out16), M, N, K, epi, resid, N, rf16, gm, N, rpg, 1, 0, 0, 0)
+    got = out.double().cpu()
+    tol = 2e-6 * mag + 1e-6 + (ref.abs() * 2.0 ** -10 if out16 else 0)      # fp32 accumulation (+ one fp16 rounding of the result)
+    if mode == 'resid32': tol = tol * gamma.double().repeat_interleave(rpg, dim=0)[:M].abs().clamp_min(1.0) + 1e-6 * ref.abs()
+    bad = (got - ref).abs() > tol
+    assert not bool(bad.any()), f'{mode} {M}x{N}x{K}: {int(bad.sum())} outside tolerance, max err {float((got - ref).abs().max()):.3e}'
+
+
+@pytest.mark.parametrize('B2,l,H,pos0,l2', [(4, 9, 2, 5, 1), (2, 64, 4, 91, 1), (3, 25, 16, 0, 0)])
+def test_gemm_qkv16_against_float64(B2, l, H, pos0, l2):
+    hip = _hip()
+    C, K, Lmax = H * 64, H * 64, 160
+    M = B2 * l
+    g = torch.Generator().manual_seed(B2 * 100 + l)
+    A = (torch.randn(M, K, generator=g)).half(); W = (torch.randn(3 * C, K, generator=g) * (1.0 / K ** 0.5)).half()
+    bias = torch.randn(3 * C, generator=g) * 0.1
+    smul = torch.randn(H, generator=g) * 0.3 + 1.4
+    q = torch.empty(M, C, dtype=torch.float16, device='cuda')
+    kc = torch.zeros(B2, H, Lmax, 64, dtype=torch.float16, device='cuda'); vc = torch.zeros_like(kc)
+    hip.call('gemm_qkv_f16', A.cuda(), K, W.cuda(), K, bias.cuda(), M, C, K, smul.cuda(), 0.125, l2, q, kc, vc, B2, l, H, pos0, Lmax)
+    ref = (A.double() @ W.double().T + bias.double()).view(B2, l, 3, H, 64)
+    rq, rk, rv = ref[:, :, 0], ref[:, :, 1], ref[:, :, 2]
+    if l2:
+        rq = rq / rq.norm(dim=-1, keepdim=True).clamp_min(1e-12) * smul.double().clamp_max(np.log(100)).exp().view(1, 1, H, 1)
+        rk = rk / rk.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    else:
+        rq = rq * 0.125
+    def close(a, b, name):
+        err = (a.double().cpu() - b).abs(); tol = b.abs() * 2.0 ** -10 + 2e-4
+        assert bool((err <= tol).all()), f'{name}: max err {float(err.max()):.3e}'
+    close(q.view(B2, l, H, 64), rq, 'q')
+    close(kc[:, :, pos0:pos0 + l].permute(0, 2, 1, 3), rk, 'k cache rows')
+    close(vc[:, :, pos0:pos0 + l].permute(0, 2, 1, 3), rv, 'v cache rows')
+    assert float(kc[:, :, :pos0].abs().max() if pos0 else 0) == 0 and float(kc[:, :, pos0 + l:].abs().max()) == 0
+
+
+@pytest.mark.parametrize('B2,l,H,curL', [(2, 1, 2, 1), (3, 9, 2, 14), (2, 36, 3, 91), (2, 169, 2, 424), (1, 256, 2, 680), (2, 40, 1, 33)])
+def test_attn16_against_twin(B2, l, H, curL):
+    """fp16 attention vs its CPU twin (oracle: fp32 chains, p rounded to fp16 for p.v) on the same fp16 q / K / V; peaked scores included"""
+    hip = _hip()
+    util.ensure_oracle_built()
+    from oracle.var_oracle import lib, _p
+    Lmax = curL + 7
+    g = torch.Generator().manual_seed(l * 1000 + curL)
+    q = torch.randn(B2 * l, H * 64, generator=g)
+    q = (q.view(B2 * l, H, 64) / q.view(B2 * l, H, 64).norm(dim=-1, keepdim=True) * 6.0).view(B2 * l, H * 64).half()     # |q| = scale_mul-like
+    k = torch.randn(B2, H, Lmax, 64, generator=g); k = (k / k.norm(dim=-1, keepdim=True)).half()
+    v = torch.randn(B2, H, Lmax, 64, generator=g).half()
+    out = torch.empty(B2 * l, H * 64, dtype=torch.float16, device='cuda')
+    hip.call('attn_cached_f16', q.cuda(), k.cuda(), v.cuda(), out, B2, l, H, curL, Lmax)
+    want = np.empty((B2 * l, H * 64), np.float32)
+    assert lib()['attn_cached_p16_f32'](_p(q.float().numpy()), _p(k.float().numpy()), _p(v.float().numpy()), _p(want), B2, l, H, curL, Lmax) == 0
+    got = out.float().cpu().numpy()
+    err = np.abs(got - want)
+    # p is rounded to fp16 at slightly different values (hardware exp2 vs vm_exp: ~1e-6 relative), the output is one fp16 rounding of
+    # nearly equal fp32 values: two fp16 ulps of the output magnitude
+    tol = np.abs(want) * 2.0 ** -9 + 2e-3
+    assert (err <= tol).all(), f'max err {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}'
+    # and against exact softmax attention in float64: the fp16 p rounding is the dominant deviation
+    s = torch.einsum('bthc,bhjc->bhtj', q.view(B2, l, H, 64).double(), k[:, :, :curL].double())
+    ref = torch.einsum('bhtj,bhjc->bthc', s.softmax(-1), v[:, :, :curL].double()).reshape(B2 * l, H * 64).numpy()
+    assert np.abs(got - ref).max() <= 1e-2
+
+
+_MODELS = {}
+
+
+def _models(meta):
+    key = (meta['depth'], meta['ch'], tuple(meta['patch_nums']), meta['attn_l2_norm'], meta['shared_aln'])
+    if key not in _MODELS:
+        from models import build_vae_var
+        from var_amd.detinit import fill_module_device_
+        _MODELS.clear(); torch.cuda.empty_cache()
+        with contextlib.redirect_stdout(io.StringIO()):
+            vae, var = build_vae_var(device='cuda', patch_nums=tuple(meta['patch_nums']), depth=meta['depth'], ch=meta['ch'],
+                                     shared_aln=meta['shared_aln'], attn_l2_norm=meta['attn_l2_norm'])
+        fill_module_device_(var, meta['depth'], 0, 'var.'); fill_module_device_(vae, meta['depth'], 0, 'vae.')
+        _MODELS[key] = (vae.eval(), var.eval())
+    return _MODELS[key]
+
+
+@pytest.mark.parametrize('name', ['t_pn12345', 't_saln', 't_nol2', 'd16_pn123'])
+def test_f16_mode_vs_twin_and_reference(name):
+    """end to end, teacher-forced with the reference's tokens: per-scale logits of the HIP f16 mode vs the CPU twin (same rounding points)
+    and vs the reference's fp32 run; own token choices vs the reference's as an agreement rate; image vs the reference's"""
+    z, meta = util.load_case(name)
+    vae, var = _models(meta)
+    pns = meta['patch_nums']
+    noise = [torch.from_numpy(n) for n in util.regen_noise(meta, z)]
+    labels = torch.tensor(meta['labels'], dtype=torch.int64, device='cuda')
+    force = torch.from_numpy(z['idx'].astype(np.int64))
+    var.set_hip_precision('f16')
+    try:
+        eng = var.engine()
+        img = eng.sample(len(meta['labels']), labels, None, meta['cfg'], meta['top_k'], meta['top_p'], noises=noise, force_idx=force, trace=True)
+        tr = {k: [t.cpu().numpy() for t in v] for k, v in eng.last_trace.items()}
+        img = img.cpu().numpy()
+        free = eng.sample(len(meta['labels']), labels, None, meta['cfg'], meta['top_k'], meta['top_p'], noises=noise, trace=True)
+        idx_free = torch.cat(eng.last_trace['idx'], dim=1).cpu().numpy()
+    finally:
+        var.set_hip_precision('f32')
+    util.ensure_oracle_built()
+    from oracle.var_oracle import OracleVAR
+    var_sd, vae_sd = util.make_weights(meta)
+    twin = OracleVAR(var_sd, vae_sd, pns, meta['depth'], attn_l2_norm=meta['attn_l2_norm'], shared_aln=meta['shared_aln'], f16=True)
+    r = twin.run(meta['labels'], util.regen_noise(meta, z), meta['cfg'], meta['top_k'], meta['top_p'], force_idx=z['idx'].astype(np.int64))
+    msgs, ok_all = [], True
+    for si, pn in enumerate(pns):
+        lg = tr['logits'][si]
+        scale = float(np.abs(r['logits'][si]).max())
+        ok, m = util.diff_report(f'{name} f16 logits s{si} vs twin (|logit| max {scale:.2f})', lg, r['logits'][si], atol=4e-3 * max(scale, 1.0), rtol=0); ok_all &= ok; msgs.append(m)
+        want = z[f'logits_s{si}']
+        got = lg if meta['full_logits'] else lg[:, sorted({0, pn * pn - 1}), :]
+        ok, m = util.diff_report(f'{name} f16 logits s{si} vs fp32 reference', got, want, atol=3e-2 * max(scale, 1.0), rtol=0); ok_all &= ok; msgs.append(m)
+    idx = np.concatenate(tr['idx'], axis=1)
+    agree_tf = float((idx == z['idx']).mean()); agree_twin = float((idx == r['idx']).mean()); agree_free = float((idx_free == z['idx']).mean())
+    msgs.append(f'{name}: token agreement with the fp32 reference, teacher-forced {agree_tf:.3f}, free-running {agree_free:.3f}; with the twin (teacher-forced) {agree_twin:.3f}')
+    ok, m = util.diff_report(f'{name} f16 image (teacher-forced tokens) vs reference', img, z['img'], atol=1e-3); ok_all &= ok; msgs.append(m)
+    print('\n'.join(msgs))
+    assert ok_all, '\n'.join(msgs)
+    assert agree_tf >= 0.9 and agree_twin >= 0.95, msgs[-2]
+    assert np.isfinite(free.cpu().numpy()).all()
+
+
+def test_f16_mode_properties_d16_full():
+    """d16, all 10 scales at B=4 in the 16-bit mode: deterministic, batch-slice invariant, finite; the mode switch restores fp32 results bit for bit"""
+    z, meta = util.load_case('d16_full')
+    vae, var = _models(meta)
+    V, B = var.V, 4
+    g = torch.Generator().manual_seed(5)
+    noise = [torch.empty(B * pn * pn, V).exponential_(1, generator=g) for pn in var.patch_nums]
+    labels = torch.tensor([1, 22, 333, 980], device='cuda')
+    eng = var.engine()
+    base32 = eng.sample(B, labels, None, 1.5, 900, 0.96, noises=noise).clone()
+    var.set_hip_precision('f16')
+    try:
+        a = eng.sample(B, labels, None, 1.5, 900, 0.96, noises=noise, trace=True).clone()
+        ia = torch.cat(eng.last_trace['idx'], dim=1)
+        b = eng.sample(B, labels, None, 1.5, 900, 0.96, noises=noise, trace=True)
+        assert torch.equal(a, b) and torch.equal(ia, torch.cat(eng.last_trace['idx'], dim=1))
+        sub = eng.sample(2, labels[1:3], None, 1.5, 900, 0.96, noises=[n.view(B, -1, V)[1:3].reshape(-1, V) for n in noise])
+        assert torch.equal(sub, a[1:3])
+        assert torch.isfinite(a).all() and float(a.min()) >= 0 and float(a.max()) <= 1
+    finally:
+        var.set_hip_precision('f32')
+    assert torch.equal(eng.sample(B, labels, None, 1.5, 900, 0.96, noises=noise), base32)

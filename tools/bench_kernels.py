@@ -106,6 +106,40 @@ def run_attn(iters):
         print(f'attn l={l:3d} curL={cur:3d}: {ms*1e3:9.1f} us  {tf:6.1f} TF (algorithmic)', flush=True)
 
 
+def run_gemm16(iters, rounds=3):
+    """the 16-bit mode's GEMM (varhip_gemm_nt_f16) at the d16 / B=64 shapes; TFLOP/s against the 2.5 PF dense fp16 peak"""
+    dev = 'cuda'
+    res, bufs = {}, {}
+    shapes = [s_ for s_ in gemm_shapes() if s_[1] >= 2048]
+    for name, M, N, K, epi in shapes:
+        A = torch.randn(M, K, device=dev).half(); W = (torch.randn(N, K, device=dev) * 0.03).half(); b = torch.randn(N, device=dev)
+        out16 = torch.empty(M, N, device=dev, dtype=torch.float16); out32 = torch.empty(M, N, device=dev); resid = torch.randn(M, N, device=dev); gamma = torch.randn(128, N, device=dev)
+        bufs[name] = (A, W, b, out16, out32, resid, gamma)
+    for r in range(rounds):
+        for name, M, N, K, epi in shapes:
+            A, W, b, out16, out32, resid, gamma = bufs[name]
+            rpg = max(M // 128, 1)
+            o16 = 0 if epi == 2 else 1
+            fn = lambda: hip.call('gemm_nt_f16', A, K, W, K, b, out16 if o16 else out32, N, o16, M, N, K, epi, resid if epi == 2 else None, N, 0, gamma if epi == 2 else None, N, rpg, 1, 0, 0, 0)
+            res.setdefault(name, []).append(timeit(fn, iters * 2))
+    for name, M, N, K, epi in shapes:
+        ms = min(res[name]); tf = 2.0 * M * N * K / ms / 1e9
+        print(f'gemm16 {name:14s} M={M:6d} N={N:5d} K={K:5d} epi={epi}: {ms*1e3:9.1f} us  {tf:7.1f} TF  {tf/2500*100:5.1f}% of 2.5 PF', flush=True)
+
+
+def run_attn16(iters):
+    dev = 'cuda'
+    B2, H, Lmax = 128, 16, 680
+    kc = torch.randn(B2, H, Lmax, 64, device=dev).half(); vc = torch.randn(B2, H, Lmax, 64, device=dev).half()
+    cur = 0
+    for pn in (1, 2, 3, 4, 5, 6, 8, 10, 13, 16):
+        l = pn * pn; cur += l
+        q = torch.randn(B2 * l, H * 64, device=dev).half(); out = torch.empty_like(q)
+        fn = lambda: hip.call('attn_cached_f16', q, kc, vc, out, B2, l, H, cur, Lmax)
+        ms = timeit(fn, iters); tf = 4.0 * B2 * H * l * cur * 64 / ms / 1e9
+        print(f'attn16 l={l:3d} curL={cur:3d}: {ms*1e3:9.1f} us  {tf:6.1f} TF (algorithmic)', flush=True)
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('what', nargs='?', default='all')
@@ -117,3 +151,5 @@ if __name__ == '__main__':
     if a.what in ('qkv', 'all'): run_qkv(a.iters)
     if a.what in ('conv', 'all'): run_conv(a.iters)
     if a.what in ('attn', 'all'): run_attn(a.iters)
+    if a.what in ('gemm16', 'all16'): run_gemm16(a.iters)
+    if a.what in ('attn16', 'all16'): run_attn16(a.iters)

@@ -52,6 +52,15 @@ SIGNATURES = {
     'smooth_select_f32': [P, P, P, P, I, I, I, F, F, I, I, I, D, P, P, P, P],
 }
 
+# the 16-bit throughput mode: HIP library only (its CPU twin is oracle/var_oracle.py with f16=True: the fp32 functions + rounding points)
+SIGNATURES_F16 = {
+    'gemm_nt_f16':       [P, L, P, L, P, P, L, I, I, I, I, I, P, L, I, P, L, I, I, L, L, L],
+    'gemm_qkv_f16':      [P, L, P, L, P, I, I, I, P, F, I, P, P, P, I, I, I, I, I],
+    'attn_cached_f16':   [P, P, P, P, I, I, I, I, I],
+    'ln_modulate_f16out': [P, P, L, P, L, P, I, I, I, F],
+    'adaln_block_f16':   [P, P, P, P, P, P, P, L, P, P, P, F, I, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, F],
+}
+
 EPI_NONE, EPI_GELU, EPI_RESID = 0, 1, 2
 EINVAL = -1
 
@@ -59,7 +68,10 @@ EINVAL = -1
 def bind(lib, prefix: str, with_stream: bool):
     """Attach argtypes/restype to every ABI function of `lib`; raises AttributeError naming a missing symbol."""
     fns = {}
-    for name, args in SIGNATURES.items():
+    table = dict(SIGNATURES)
+    if with_stream:                      # the HIP library also carries the 16-bit mode
+        table.update(SIGNATURES_F16)
+    for name, args in table.items():
         fn = getattr(lib, prefix + name)
         fn.argtypes = list(args) + ([P] if with_stream else [])
         fn.restype = I

@@ -1,0 +1,207 @@
+// attn16.hip — attention of the 16-bit throughput mode: fp16 q / K cache / V cache, fp32 scores, softmax statistics and output
+// accumulators, v_mfma_f32_32x32x16_f16 for both products (the reference under its harness' fp16 autocast takes the flash-attention
+// path with fp16 q, k, v: basic_var.py:97,113).  Not part of the fp32 parity contract; compared with the CPU twin with a tolerance.
+//
+// Rounding points of this mode: q, k, v are fp16 (written by varhip_gemm_qkv_f16); scores accumulate in fp32; p = exp(s - m) in fp32
+// (hardware exp2), the row sum adds the fp32 p; p is rounded to fp16 for the second product; O accumulates in fp32; out = O / l -> fp16.
+//
+// Structure as attn.hip: one workgroup per (sample, head), NW waves x 32 queries, "swapped" scores S^T = K_tile . Q^T so that a lane owns
+// one query; 32-key tiles with the running maximum.  A 32x32x16 step contracts 16 k: lane (row, half h) supplies k = 8h .. 8h+7 as one
+// 16-byte fragment.  The score accumulators of a lane (C layout: register e = key (e & 3) + 8 (e >> 2) + 4h) become the B operand of the
+// second product by pairwise conversion to fp16 (registers 8s .. 8s+7 = the fragment of step s); the V^T fragment of that step is stored
+// in LDS in the matching key order (cdna_hip_programming.md §3, "an accumulator tile as the next MFMA's operand").
+#include "common.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+
+#define VLD16 40          // halves per V^T row: 32 keys + 8 pad (80 bytes: ds_read_b128 of 16 channel rows hits 16 different slots)
+#define OLD16 72          // halves per row of the output staging tile (64 + 8 pad)
+
+__device__ __forceinline__ void vh16a_dma16(const void* base, uint32_t voff, uint32_t lds) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(base), "s"(lds) : "memory", "m0");
+}
+__device__ __forceinline__ float vh16a_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
+template <int NW>
+__global__ void __launch_bounds__(NW * 64, NW) k_attn16(const _Float16* __restrict__ q, const _Float16* __restrict__ kcache, const _Float16* __restrict__ vcache,
+                                                         _Float16* __restrict__ out, int l, int H, int curL, int Lmax) {
+    constexpr int NT = NW * 64, NIT = (256 + NT - 1) / NT;
+    constexpr int KST = 32 * 128, VST = 64 * VLD16 * 2;           // bytes per K / V stage
+    __shared__ __attribute__((aligned(16))) char smem[2 * KST + 2 * VST];
+    char* sK = smem;
+    char* sV = smem + 2 * KST;
+    static_assert(4 * 32 * OLD16 * 2 <= 2 * KST + 2 * VST, "O staging must fit in the K/V stages");
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h2 = lane >> 5;
+    const int b = blockIdx.z, hd = blockIdx.y;
+    const int C = H * 64;
+    const int t0 = (blockIdx.x * NW + wave) * 32;
+    const _Float16* Kc = kcache + ((int64_t)b * H + hd) * Lmax * 64;
+    const _Float16* Vc = vcache + ((int64_t)b * H + hd) * Lmax * 64;
+    const int ntile = (curL + 31) / 32;
+
+    // Q fragments: lane (query r, half h), step t: q[16t + 8h .. + 7]
+    h8 qf[4];
+    {
+        const int t = t0 + r;
+        const _Float16* src = q + ((int64_t)b * l + (t < l ? t : 0)) * C + hd * 64 + h2 * 8;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *(const h8*)(src + s * 16);
+    }
+
+    // K tile by LDS-DMA: 4 pieces of 8 key rows (1 KiB); slot c of row rr holds source chunk c ^ ((rr >> 1) & 7) (conflict-free b128 reads)
+    auto dma_k = [&](int kt, int st) {
+#pragma unroll
+        for (int i = 0; i < (4 + NW - 1) / NW; ++i) {
+            const int n = wave + i * NW;
+            if (n >= 4) break;
+            const int rr = n * 8 + (lane >> 3);
+            int key = kt * 32 + rr; key = key < curL ? key : curL - 1;
+            vh16a_dma16(Kc, (uint32_t)key * 128u + (uint32_t)(((lane & 7) ^ ((rr >> 1) & 7)) << 4),
+                        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(sK + st * KST + n * 1024));
+        }
+    };
+    // V tile through registers: item = (key row, 8-channel chunk); stored transposed, V^T[channel][pos(key)] with
+    // pos(key) = 16 (key >> 4) + 8 ((key >> 2) & 1) + 4 ((key >> 3) & 1) + (key & 3): the 8 keys of (step s, half h) are contiguous at 16s + 8h
+    h8 gv[NIT];
+    auto load_v = [&](int kt) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int item = tid + it * NT, sr = item >> 3, sc = item & 7, key = kt * 32 + sr;
+            gv[it] = (h8)(_Float16)0.f;
+            if ((NIT * NT == 256 || item < 256) && key < curL) gv[it] = *(const h8*)(Vc + (int64_t)key * 64 + sc * 8);
+        }
+    };
+    auto store_v = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int item = tid + it * NT, sr = item >> 3, sc = item & 7;
+            if (NIT * NT != 256 && item >= 256) continue;
+            const int pos = ((sr >> 4) << 4) + (((sr >> 2) & 1) << 3) + (((sr >> 3) & 1) << 2) + (sr & 3);
+            _Float16* dv = (_Float16*)(sV + buf * VST) + (sc * 8) * VLD16 + pos;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dv[e * VLD16] = gv[it][e];
+        }
+    };
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; }
+    float lsum = 0.f, mx = -INFINITY;                               // mx in units of log2: (max score) * log2(e)
+    const float LOG2E = 1.44269504088896341f;
+    dma_k(0, 0); load_v(0); store_v(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int kxor = (r >> 1) & 7;
+    for (int kt = 0; kt < ntile; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < ntile) { dma_k(kt + 1, buf ^ 1); load_v(kt + 1); }
+        if (t0 < l) {
+            f32x16 p;
+            {
+                const char* kb = sK + buf * KST + r * 128;
+                h8 kf = *(const h8*)(kb + (((0 + h2) ^ kxor) << 4));
+                p = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[0], (f32x16)(0.f), 0, 0, 0);
+#pragma unroll
+                for (int s = 1; s < 4; ++s) {
+                    kf = *(const h8*)(kb + (((2 * s + h2) ^ kxor) << 4));
+                    p = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], p, 0, 0, 0);
+                }
+            }
+            const bool ragged = kt * 32 + 32 > curL;
+            if (ragged) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h2;
+                    if (key >= curL) p[e] = -INFINITY;
+                }
+            }
+            float tmax = vh16a_max3(p[0], p[1], p[2]);
+#pragma unroll
+            for (int e = 3; e < 15; e += 2) tmax = vh16a_max3(tmax, p[e], p[e + 1]);
+            tmax = fmaxf(tmax, p[15]);
+            {
+                auto xr = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+                const float mnew = vh16a_max3(mx, __uint_as_float(xr[0]) * LOG2E, __uint_as_float(xr[1]) * LOG2E);
+                if (__any(mnew != mx)) {
+                    const float alpha = __builtin_amdgcn_exp2f(mx - mnew);       // first tile: exp2(-inf) = 0, O = l = 0
+                    lsum = lsum * alpha;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) { o0[e] = o0[e] * alpha; o1[e] = o1[e] * alpha; }
+                }
+                mx = mnew;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { p[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(p[e], LOG2E, -mx)); lsum = lsum + p[e]; }   // masked keys: exp2(-inf) = 0
+            // P -> fp16 B fragments: registers 8s .. 8s+7 of this lane = keys 16s + 8(j >> 2) + 4h + (j & 3), j = 0..7
+            h8 pf[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[s][j] = (_Float16)p[8 * s + j];
+            const char* vb = sV + buf * VST + (r * VLD16 + h2 * 8) * 2;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const h8 v0 = *(const h8*)(vb + s * 32), v1 = *(const h8*)(vb + 32 * VLD16 * 2 + s * 32);     // channels r and r + 32
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, pf[s], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, pf[s], o1, 0, 0, 0);
+            }
+        }
+        if (kt + 1 < ntile) store_v(buf ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    float inv;
+    {
+        auto xr = __builtin_amdgcn_permlane32_swap(__float_as_uint(lsum), __float_as_uint(lsum), false, false);
+        inv = 1.0f / (__uint_as_float(xr[0]) + __uint_as_float(xr[1]));
+    }
+    // O^T accumulators: col (lane & 31) = query, row = channel.  fp16, transposed through LDS, stored as 128-byte rows (16 B per lane).
+    {
+        _Float16* st = (_Float16*)smem + wave * 32 * OLD16;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            h4 a, c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[e] = (_Float16)(o0[4 * g + e] * inv); c[e] = (_Float16)(o1[4 * g + e] * inv); }
+            *(h4*)(st + r * OLD16 + 8 * g + 4 * h2) = a;               // channels 8g + 4h .. + 3
+            *(h4*)(st + r * OLD16 + 32 + 8 * g + 4 * h2) = c;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int qi = it * 8 + (lane >> 3), t = t0 + qi;
+            if (t < l) *(h8*)(out + ((int64_t)b * l + t) * C + hd * 64 + (lane & 7) * 8) = *(const h8*)(st + qi * OLD16 + (lane & 7) * 8);
+        }
+    }
+}
+
+static int attn16_waves(int l) {
+    const int nq = (l + 31) / 32;
+    int best = 4, waste = ((nq + 3) / 4) * 4 - nq;
+    for (int nw = 3; nw >= 1; --nw) { const int w = ((nq + nw - 1) / nw) * nw - nq; if (w < waste) { waste = w; best = nw; } }
+    return best;
+}
+
+extern "C" int varhip_attn_cached_f16(const void* q, const void* kcache, const void* vcache, void* out,
+                                      int B2, int l, int H, int curL, int Lmax, varhip_stream_t stream) {
+    if (B2 <= 0 || l <= 0 || H <= 0 || curL <= 0 || curL > Lmax) return VARHIP_EINVAL;
+    if (B2 > 65535 || H > 65535 || (((uintptr_t)q | (uintptr_t)kcache | (uintptr_t)vcache | (uintptr_t)out) & 15)) return VARHIP_EINVAL;
+    VhScope sc(VH_FAM_ATTN, (hipStream_t)stream, 4.0 * B2 * H * (double)l * curL * 64, 2.0 * B2 * H * (2.0 * curL * 64 + 2.0 * l * 64));
+    const int nw = attn16_waves(l);
+    dim3 grid((l + nw * 32 - 1) / (nw * 32), H, B2);
+    hipStream_t s = (hipStream_t)stream;
+    const _Float16 *q_ = (const _Float16*)q, *k_ = (const _Float16*)kcache, *v_ = (const _Float16*)vcache;
+    _Float16* o_ = (_Float16*)out;
+    switch (nw) {
+        case 1: hipLaunchKernelGGL((k_attn16<1>), grid, dim3(64), 0, s, q_, k_, v_, o_, l, H, curL, Lmax); break;
+        case 2: hipLaunchKernelGGL((k_attn16<2>), grid, dim3(128), 0, s, q_, k_, v_, o_, l, H, curL, Lmax); break;
+        case 3: hipLaunchKernelGGL((k_attn16<3>), grid, dim3(192), 0, s, q_, k_, v_, o_, l, H, curL, Lmax); break;
+        default: hipLaunchKernelGGL((k_attn16<4>), grid, dim3(256), 0, s, q_, k_, v_, o_, l, H, curL, Lmax); break;
+    }
+    return vh_launch_status();
+}

@@ -1,0 +1,261 @@
+// gemm16.hip — the 16-bit-input throughput mode of the transformer GEMMs: fp16 operands, fp32 accumulation on
+// v_mfma_f32_16x16x32_f16 (the mode the reference's own harness runs in: demo_sample.py:66-68 wraps the call in
+// torch.autocast('cuda', dtype=torch.float16), under which every F.linear of basic_var.py computes in fp16).
+//
+// NOT part of the fp32 parity contract: the MFMA-internal reduction over 32 k is not a k-ascending fma chain, so results agree
+// with the CPU twin (oracle/var_oracle.py, f16 mode: same rounding points, fp32 chains) to rounding noise, not bit for bit.
+// Rounding points (the contract of this mode): A and W are fp16; products are exact in fp32; accumulation fp32; bias, GELU,
+// gamma and the residual add in fp32; ONE rounding to fp16 where the output is fp16.
+//
+// Data path = k_dma_gemm of gemm.hip at the same byte geometry: a K tile is 64 halves = 128 bytes per row, both operand tiles go
+// global -> LDS by LDS-DMA (16 B per lane, bank swizzle on the source side: slot c of row r holds chunk c ^ (r & 7)), two LDS
+// stages, one barrier per K tile, weights as the A operand so that a lane ends with 4 consecutive n of one row.  A lane's operand
+// fragment of a 16x16x32 step is 8 consecutive k = one 16-byte chunk: one ds_read_b128 per 16-row fragment and step
+// (conflict-free with that swizzle), two steps per K tile.
+#include "common.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+struct Gemm16P {
+    const _Float16* A; const _Float16* W; const float* bias; void* out; const void* resid; const float* gamma;
+    int64_t lda, ldw, ldo, ldr, ldg, sA, sW, sO;
+    int M, N, K, epi, rows_per_group, out_f16, resid_f16;
+    int tilesM, tilesN;
+    // epi == 3: fused q/k/v epilogue (N = 3C, head_dim 64)
+    const float* q_smul; _Float16* q_out; _Float16* q_kc; _Float16* q_vc; float q_plain; int q_l2, q_l, q_pos0, q_Lmax;
+};
+
+template <int N> __device__ __forceinline__ void vh16_waitcnt_barrier() { asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void vh16_dma16(const void* base, uint32_t voff, uint32_t lds) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(base), "s"(lds) : "memory", "m0");
+}
+
+// GELU (tanh form) for the fp16 output of fc1: x * sigmoid(2u), u = sqrt(2/pi)(x + 0.044715 x^3), with the hardware exp2 / reciprocal
+// (this mode is not bit-compared; the twin uses the same formula with libm: difference ~1e-7 relative, far below the fp16 rounding)
+__device__ __forceinline__ float vh16_gelu(float x) {
+    const float u = 0.7978845608028654f * (x + 0.044715f * ((x * x) * x));
+    const float e = __builtin_amdgcn_exp2f(u * -2.8853900817779268f);         // exp(-2u)
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+template <int TMW, int TNW>
+__global__ void __launch_bounds__(256) k_gemm16(Gemm16P p) {
+    constexpr int BM = TMW * 32, BN = TNW * 32, ROWB = 128, STAGE = (BM + BN) * ROWB;      // bytes
+    constexpr int NIA = BM / 32, NIB = BN / 32;                                            // DMA instructions per wave and K tile
+    extern __shared__ __attribute__((aligned(16))) char smem16[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int tm_, tn_;
+    {   // XCD-contiguous, grouped block order (as k_dma_gemm)
+        const int nwg = p.tilesM * p.tilesN, bid = blockIdx.x;
+        const int q = nwg >> 3, rem = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        const int lin = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + loc;
+        const int GM = 8, width = GM * p.tilesN, group = lin / width, first = group * GM;
+        const int gsz = (p.tilesM - first) < GM ? (p.tilesM - first) : GM;
+        tm_ = first + (lin % width) % gsz;
+        tn_ = (lin % width) / gsz;
+    }
+    const int m0 = tm_ * BM, n0 = tn_ * BN, bz = blockIdx.z;
+    const char* Ab = (const char*)(p.A + (int64_t)bz * p.sA);
+    const char* Wb = (const char*)(p.W + (int64_t)bz * p.sW);
+
+    const int drow = lane >> 3, dslot = lane & 7;
+    uint32_t aoff[NIA], boff[NIB];
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) {
+        int m = m0 + wave * (BM / 4) + i * 8 + drow; m = m < p.M ? m : p.M - 1;
+        aoff[i] = (uint32_t)((int64_t)m * p.lda * 2 + ((dslot ^ drow) << 4));
+    }
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) {
+        int n = n0 + wave * (BN / 4) + i * 8 + drow; n = n < p.N ? n : p.N - 1;
+        boff[i] = (uint32_t)((int64_t)n * p.ldw * 2 + ((dslot ^ drow) << 4));
+    }
+    auto dma_tile = [&](int kt, int st) {
+        char* sA = smem16 + st * STAGE + wave * (BM / 4) * ROWB;
+        char* sB = smem16 + st * STAGE + BM * ROWB + wave * (BN / 4) * ROWB;
+#pragma unroll
+        for (int i = 0; i < NIA; ++i)
+            vh16_dma16(Ab + (size_t)kt * ROWB, aoff[i], (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(sA + i * 8 * ROWB));
+#pragma unroll
+        for (int i = 0; i < NIB; ++i)
+            vh16_dma16(Wb + (size_t)kt * ROWB, boff[i], (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(sB + i * 8 * ROWB));
+    };
+
+    f32x4 acc[TMW][TNW];
+#pragma unroll
+    for (int i = 0; i < TMW; ++i)
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int nk = p.K / 64;
+    const bool idle_wave = (n0 + wn * TNW * 16 >= p.N) || (m0 + wm * TMW * 16 >= p.M);
+    auto compute = [&](int cur, auto&& mid) {
+        const char* sA = smem16 + cur * STAGE + (wm * TMW * 16 + r16) * ROWB;
+        const char* sB = smem16 + cur * STAGE + BM * ROWB + (wn * TNW * 16 + r16) * ROWB;
+        h8 am[2][TMW], bn[2][TNW];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int sl = ((4 * s + kq) ^ (r16 & 7)) << 4;          // rows i*16 + r16: (row & 7) == (r16 & 7)
+#pragma unroll
+            for (int i = 0; i < TMW; ++i) am[s][i] = *(const h8*)(sA + i * 16 * ROWB + sl);
+#pragma unroll
+            for (int j = 0; j < TNW; ++j) bn[s][j] = *(const h8*)(sB + j * 16 * ROWB + sl);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int i = 0; i < TMW; ++i)
+#pragma unroll
+                for (int j = 0; j < TNW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bn[s][j], am[s][i], acc[i][j], 0, 0, 0);
+            if (s == 0) mid();
+        }
+    };
+    dma_tile(0, 0);
+    vh16_waitcnt_barrier<0>();
+    if (idle_wave) {
+        for (int kt = 0; kt < nk; ++kt) { if (kt + 1 < nk) dma_tile(kt + 1, (kt & 1) ^ 1); vh16_waitcnt_barrier<0>(); }
+    } else {
+        int kt = 0;
+        for (; kt + 1 < nk; kt += 2) {
+            compute(0, [&] { dma_tile(kt + 1, 1); });
+            vh16_waitcnt_barrier<0>();
+            compute(1, [&] { if (kt + 2 < nk) dma_tile(kt + 2, 0); });
+            vh16_waitcnt_barrier<0>();
+        }
+        if (kt < nk) { compute(0, [] {}); vh16_waitcnt_barrier<0>(); }
+    }
+
+    // ---- epilogue: acc[i][j][e] = C[m = tile_m(i) + r16][n = tile_n(j) + 4*kq + e]
+    const int nw0 = n0 + wn * TNW * 16;
+    if (nw0 >= p.N) return;
+    if constexpr (TNW == 4) {
+        if (p.epi == 3) {
+            // fused q/k/v post-processing (basic_var.py:98-109): the wave's 64 columns are one head of q, k or v.  L2 norm, scale and the
+            // sum of squares in fp32 on the accumulators; q and the cache rows leave as fp16.
+            const int C = p.N / 3, sect = nw0 / C, head = (nw0 - sect * C) >> 6, Hh = C >> 6;
+            f32x4 b4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b4[j] = p.bias ? *(const f32x4*)(p.bias + nw0 + j * 16 + kq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const float sm = (p.q_l2 && sect == 0) ? vm_exp(vm_min(p.q_smul[head], 4.605170249938965f)) : 1.0f;
+#pragma unroll
+            for (int i = 0; i < TMW; ++i) {
+                const int m = m0 + (wm * TMW + i) * 16 + r16;
+                f32x4 v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[i][j] + b4[j];
+                if (p.q_l2 && sect < 2) {
+                    const f32x4 a0 = v[0] * v[0] + v[2] * v[2], a1 = v[1] * v[1] + v[3] * v[3];
+                    f32x4 b = a0 + a1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) b[e] = b[e] + __shfl_xor(b[e], 32, 64);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) b[e] = b[e] + __shfl_xor(b[e], 16, 64);
+                    const float t0 = b[0] + b[2], t1 = b[1] + b[3];
+                    const float rn = (sect == 0 ? sm : 1.0f) / vm_max(vm_sqrt(t0 + t1), 1e-12f);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = v[j] * rn;
+                } else if (!p.q_l2 && sect == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = v[j] * p.q_plain;
+                }
+                if (m >= p.M) continue;
+                _Float16* dst;
+                if (sect == 0) dst = p.q_out + (int64_t)m * C + head * 64;
+                else {
+                    const int bb = m / p.q_l, t = m - bb * p.q_l;
+                    dst = (sect == 1 ? p.q_kc : p.q_vc) + (((int64_t)bb * Hh + head) * p.q_Lmax + p.q_pos0 + t) * 64;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    h4 o; o[0] = (_Float16)v[j][0]; o[1] = (_Float16)v[j][1]; o[2] = (_Float16)v[j][2]; o[3] = (_Float16)v[j][3];
+                    *(h4*)(dst + j * 16 + kq * 4) = o;
+                }
+            }
+            return;
+        }
+    }
+    char* Ob = (char*)p.out + (int64_t)bz * p.sO * (p.out_f16 ? 2 : 4);
+#pragma unroll
+    for (int j = 0; j < TNW; ++j) {
+        const int n = nw0 + j * 16 + kq * 4;
+        if (n >= p.N) continue;                                     // (N % 4 == 0: host-checked)
+        const f32x4 b4 = p.bias ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < TMW; ++i) {
+            const int m = m0 + (wm * TMW + i) * 16 + r16;
+            if (m >= p.M) continue;
+            f32x4 v = acc[i][j] + b4;
+            if (p.epi == VARHIP_EPI_GELU) { v[0] = vh16_gelu(v[0]); v[1] = vh16_gelu(v[1]); v[2] = vh16_gelu(v[2]); v[3] = vh16_gelu(v[3]); }
+            else if (p.epi == VARHIP_EPI_RESID) {
+                if (p.gamma) v = v * *(const f32x4*)(p.gamma + (int64_t)(m / p.rows_per_group) * p.ldg + n);
+                if (p.resid_f16) { const h4 r4 = *(const h4*)((const _Float16*)p.resid + (int64_t)m * p.ldr + n);
+                                   v[0] = (float)r4[0] + v[0]; v[1] = (float)r4[1] + v[1]; v[2] = (float)r4[2] + v[2]; v[3] = (float)r4[3] + v[3]; }
+                else v = *(const f32x4*)((const float*)p.resid + (int64_t)m * p.ldr + n) + v;
+            }
+            if (p.out_f16) { h4 o; o[0] = (_Float16)v[0]; o[1] = (_Float16)v[1]; o[2] = (_Float16)v[2]; o[3] = (_Float16)v[3];
+                             *(h4*)(Ob + ((int64_t)m * p.ldo + n) * 2) = o; }
+            else *(f32x4*)(Ob + ((int64_t)m * p.ldo + n) * 4) = v;
+        }
+    }
+}
+
+template <int TMW, int TNW>
+static int launch16(Gemm16P& p, int batch, hipStream_t stream) {
+    constexpr int BM = TMW * 32, BN = TNW * 32;
+    constexpr size_t lds = 2 * (size_t)(BM + BN) * 128;
+    p.tilesM = (p.M + BM - 1) / BM; p.tilesN = (p.N + BN - 1) / BN;
+    auto kfn = k_gemm16<TMW, TNW>;
+    static bool attr_done = false;
+    if (!attr_done) { if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+    hipLaunchKernelGGL(kfn, dim3(p.tilesM * p.tilesN, 1, batch), dim3(256), lds, stream, p);
+    return vh_launch_status();
+}
+
+static int pick_tile16(int M, int N, int batch) {
+    // 128x128 when it fills the chip at least twice over, else 64x64 (K cannot be split without a reduction pass; the small scales are
+    // weight-streaming bound anyway)
+    const int64_t nb128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128) * batch;
+    return nb128 >= 512 ? 0 : 1;
+}
+
+extern "C" int varhip_gemm_nt_f16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                                  void* out, int64_t ldo, int out_f16, int M, int N, int K, int epi,
+                                  const void* resid, int64_t ldr, int resid_f16, const float* gamma, int64_t ldg, int rows_per_group,
+                                  int batch, int64_t sA, int64_t sW, int64_t sO, varhip_stream_t stream) {
+    if (M < 0 || N <= 0 || K <= 0 || batch < 1 || (K & 63) || (N & 3)) return VARHIP_EINVAL;
+    if ((lda & 7) || (ldw & 7) || (sA & 7) || (sW & 7) || (((uintptr_t)A | (uintptr_t)W) & 15)) return VARHIP_EINVAL;
+    if (((int64_t)(M > 0 ? M - 1 : 0) * lda + K) * 2 >= (1ll << 32) || ((int64_t)(N - 1) * ldw + K) * 2 >= (1ll << 32)) return VARHIP_EINVAL;
+    if (epi < 0 || epi > 2 || (epi == VARHIP_EPI_RESID && !resid) || (batch > 1 && (resid || gamma))) return VARHIP_EINVAL;
+    if ((ldo & 3) || (sO & 3) || ((uintptr_t)out & 15) || (bias && ((uintptr_t)bias & 15)) || (resid && ((ldr & 3) || ((uintptr_t)resid & 15))) ||
+        (gamma && ((ldg & 3) || ((uintptr_t)gamma & 15)))) return VARHIP_EINVAL;
+    if (M == 0) return 0;
+    Gemm16P p{};
+    p.A = (const _Float16*)A; p.W = (const _Float16*)W; p.bias = bias; p.out = out; p.resid = resid; p.gamma = gamma;
+    p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.ldr = ldr; p.ldg = ldg; p.sA = sA; p.sW = sW; p.sO = sO;
+    p.M = M; p.N = N; p.K = K; p.epi = epi; p.rows_per_group = rows_per_group > 0 ? rows_per_group : 1; p.out_f16 = out_f16; p.resid_f16 = resid_f16;
+    const int pick = pick_tile16(M, N, batch);
+    VhScope scope(pick == 0 ? VH_FAM_GEMM : VH_FAM_GEMM_SMALL, (hipStream_t)stream, 2.0 * M * N * (double)K * batch,
+                  batch * (2.0 * ((double)M * K + (double)N * K) + (out_f16 ? 2.0 : 4.0) * (double)M * N));
+    return pick == 0 ? launch16<4, 4>(p, batch, (hipStream_t)stream) : launch16<2, 2>(p, batch, (hipStream_t)stream);
+}
+
+// mat_qkv in the 16-bit mode: fp16 x fp16 -> fp32 accumulators -> (+bias, q/k L2 norm, scale) in fp32 -> fp16 q and fp16 KV-cache rows
+extern "C" int varhip_gemm_qkv_f16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, int M, int C, int K,
+                                   const float* scale_mul, float plain_scale, int l2norm,
+                                   void* q_out, void* kcache, void* vcache, int B2, int l, int H, int pos0, int Lmax, varhip_stream_t stream) {
+    if (B2 <= 0 || l <= 0 || H <= 0 || pos0 < 0 || pos0 + l > Lmax || (l2norm && !scale_mul)) return VARHIP_EINVAL;
+    if (C != H * 64 || M != B2 * l || K <= 0 || (K & 63) || (lda & 7) || (ldw & 7)) return VARHIP_EINVAL;
+    if (((int64_t)(M - 1) * lda + K) * 2 >= (1ll << 32) || ((int64_t)(3 * C - 1) * ldw + K) * 2 >= (1ll << 32)) return VARHIP_EINVAL;
+    if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)bias | (uintptr_t)q_out | (uintptr_t)kcache | (uintptr_t)vcache) & 15)) return VARHIP_EINVAL;
+    Gemm16P p{};
+    p.A = (const _Float16*)A; p.W = (const _Float16*)W; p.bias = bias; p.lda = lda; p.ldw = ldw;
+    p.M = M; p.N = 3 * C; p.K = K; p.epi = 3; p.rows_per_group = 1;
+    p.q_smul = scale_mul; p.q_out = (_Float16*)q_out; p.q_kc = (_Float16*)kcache; p.q_vc = (_Float16*)vcache; p.q_plain = plain_scale;
+    p.q_l2 = l2norm; p.q_l = l; p.q_pos0 = pos0; p.q_Lmax = Lmax;
+    const bool big = (int64_t)((M + 127) / 128) * ((3 * C + 127) / 128) >= 512;
+    VhScope scope(big ? VH_FAM_GEMM : VH_FAM_GEMM_SMALL, (hipStream_t)stream, 2.0 * M * 3.0 * C * (double)K, 2.0 * ((double)M * K + 3.0 * C * K + 3.0 * M * C));
+    return big ? launch16<4, 4>(p, 1, (hipStream_t)stream) : launch16<2, 4>(p, 1, (hipStream_t)stream);
+}

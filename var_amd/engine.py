@@ -216,6 +216,18 @@ class DecoderEngine(_VaeOps):
                 hw *= 4; f += c3(f'decoder.up.{lev}.upsample.conv', hw)
         return f + c3('decoder.conv_out', hw)
 
+    def flops_per_image_executed(self, P: int) -> float:
+        """FLOPs the kernels execute for one decode: as flops_per_image_reference, with the Upsample2x convolutions in their folded
+        four-phase form (4 taps per output pixel instead of 9)"""
+        f = self.flops_per_image_reference(P)
+        hw = P * P
+        for lev in reversed(range(self.nlev)):
+            if lev != 0:
+                hw *= 4
+                co, _, _, ci = self.w[f'decoder.up.{lev}.upsample.conv.weight'].shape
+                f -= 2.0 * hw * co * 5 * ci
+        return f
+
     def decode_nhwc(self, f_hat: torch.Tensor, denorm: bool = True) -> torch.Tensor:
         """[B,P,P,Cvae] channels-last -> [B,3,16P,16P]; denorm=True: in [0,1] (clamp and (x+1)/2 fused into the last conv, what
         autoregressive_infer_cfg returns); denorm=False: clamped to [-1,1] (VQVAE.fhat_to_img's contract)"""
@@ -403,6 +415,7 @@ class SamplingEngine:
         self.var = var
         self._sig = None
         self._ws: Dict[int, dict] = {}
+        self.precision = 'f32'              # 'f16': the 16-bit throughput mode of the transformer (include/var_hip.h "f16"), explicitly selected
         self.dec = var.vae_proxy[0]._decoder_engine()       # the VQVAE's own engine: one packed copy of the decoder weights, one place to invalidate
         self.last_trace: Optional[dict] = None
 
@@ -441,8 +454,13 @@ class SamplingEngine:
                 d['gss'] = g(b.ada_gss, 'ada_gss').view(-1)
             else:
                 d['ada_w'], d['ada_b'] = g(b.ada_lin[1].weight, 'ada_lin'), g(b.ada_lin[1].bias, 'ada_lin')
+            if self.precision == 'f16':      # fp16 copies of the four GEMM weights (round-to-nearest-even, once per weight change)
+                for k in ('qkv_w', 'proj_w', 'fc1_w', 'fc2_w'):
+                    d[k + '16'] = d[k].to(torch.float16).contiguous()
             blocks.append(d)
         w['blocks'] = blocks
+        if self.precision == 'f16':
+            w['head_w16'] = w['head_w'].to(torch.float16).contiguous()
         w['codebook'] = g(quant.embedding.weight, 'codebook')
         w['codebook_T'] = w['codebook'].t().contiguous()          # [Cvae][V]: "probabilities @ codebook" as an NT GEMM (more_smooth)
         phis = list(quant.quant_resi.phis())
@@ -455,6 +473,18 @@ class SamplingEngine:
                 w['taps'][pn] = (torch.from_numpy(ti).to(dev), torch.from_numpy(tw).to(dev))
         self.w = w
         self._sig = sig
+
+    def set_precision(self, precision: str):
+        """'f32' (default; the parity contract: token ids bit-identical to the CPU oracle) or 'f16': fp16 weights / GEMM operands / KV
+        cache with fp32 accumulation on the f16 MFMAs — what the reference's harness asks for with torch.autocast(fp16)
+        (demo_sample.py:66-68).  LayerNorm statistics, AdaLN parameters, the residual stream, softmax, sampler, quantizer and decoder stay fp32."""
+        if precision not in ('f32', 'f16'):
+            raise ValueError("precision must be 'f32' or 'f16'")
+        if precision != self.precision:
+            self.precision = precision
+            self._sig = None
+            self._ws = {}
+            if hasattr(self, '_ws_tf'): self._ws_tf = {}
 
     def invalidate(self):
         """forget the packed weight copies of the sampling loop and of the decoder (call after editing parameters through `.data`)"""
@@ -473,11 +503,12 @@ class SamplingEngine:
         M = 2 * B * lmax
         hid = var.blocks[0].ffn.fc1.weight.shape[0]
         e = lambda *s, dt=torch.float32: torch.empty(*s, dtype=dt, device=dev)
-        ws = dict(dev=dev, x=e(M, C), x2=e(M, C), xn=e(M, C), q=e(M, C), att=e(M, C), hid=e(M, hid), logits=e(M, V),
+        act = torch.float16 if self.precision == 'f16' else torch.float32       # GEMM operands and KV cache; x / x2 / logits stay fp32
+        ws = dict(dev=dev, x=e(M, C), x2=e(M, C), xn=e(M, C, dt=act), q=e(M, C, dt=act), att=e(M, C, dt=act), hid=e(M, hid, dt=act), logits=e(M, V),
                   idx=e(B * lmax, dt=torch.int64), lvl_pos=e(L, C), cond=e(2 * B, C), cond_silu=e(2 * B, C), hn=e(2 * B, 2 * C),
                   ada=e(var.depth, 2 * B, 6 * C), shared=e(2 * B, 6 * C) if var.shared_aln else None,
-                  kc=[torch.zeros(2 * B, H, L, 64, dtype=torch.float32, device=dev) for _ in range(var.depth)],
-                  vc=[torch.zeros(2 * B, H, L, 64, dtype=torch.float32, device=dev) for _ in range(var.depth)],
+                  kc=[torch.zeros(2 * B, H, L, 64, dtype=act, device=dev) for _ in range(var.depth)],
+                  vc=[torch.zeros(2 * B, H, L, 64, dtype=act, device=dev) for _ in range(var.depth)],
                   f_hat=e(B, P, P, Cv), up=e(B, P, P, Cv), pooled=e(B * lmax, Cv))
         self._ws = {B: ws}          # one batch size resident at a time
         return ws
@@ -504,10 +535,27 @@ class SamplingEngine:
         """one AdaLNSelfAttn block (basic_var.py:152-159): seven launches behind one library call; the result is left in x"""
         var = self.var
         C = var.C
+        if self.precision == 'f16':
+            hip.call('adaln_block_f16', x, x2, ws['xn'], ws['q'], ws['att'], ws['hid'], ws['ada'][bi], 6 * C,
+                     blk['qkv_w16'], blk['qkv_b'], blk['smul'], blk['plain_scale'], int(blk['l2']), blk['proj_w16'], blk['proj_b'],
+                     blk['fc1_w16'], blk['fc1_b'], blk['fc2_w16'], blk['fc2_b'], ws['kc'][bi], ws['vc'][bi],
+                     rows, l, C, var.num_heads, blk['fc1_w'].shape[0], cur, var.L, var.norm_eps)
+            return
         hip.call('adaln_block_f32', x, x2, ws['xn'], ws['q'], ws['att'], ws['hid'], ws['ada'][bi], 6 * C,
                  blk['qkv_w'], blk['qkv_b'], blk['smul'], blk['plain_scale'], int(blk['l2']), blk['proj_w'], blk['proj_b'],
                  blk['fc1_w'], blk['fc1_b'], blk['fc2_w'], blk['fc2_b'], ws['kc'][bi], ws['vc'][bi],
                  rows, l, C, var.num_heads, blk['fc1_w'].shape[0], cur, var.L, var.norm_eps)
+
+    def head(self, x, hn, xn, logits, M, l):
+        """get_logits (var.py:118-124): AdaLNBeforeHead (LayerNorm + scale/shift) then the vocabulary projection -> fp32 logits"""
+        var, w = self.var, self.w
+        C, V = var.C, var.V
+        if self.precision == 'f16':
+            hip.call('ln_modulate_f16out', x, hn, 2 * C, hn[:, C:], 2 * C, xn, M, C, l, var.norm_eps)
+            hip.call('gemm_nt_f16', xn, C, w['head_w16'], C, w['head_b'], logits, V, 0, M, V, C, EPI_NONE, None, 0, 0, None, 0, 1, 1, 0, 0, 0)
+        else:
+            hip.call('ln_modulate_f32', x, hn, 2 * C, hn[:, C:], 2 * C, xn, M, C, l, var.norm_eps)
+            self.gemm(xn, w['head_w'], w['head_b'], logits, M)
 
     def qkv(self, xn, blk, ws, bi, rows, l, cur):
         """mat_qkv + q/k normalisation + KV-cache append in one launch (basic_var.py:93-109)."""
@@ -599,9 +647,11 @@ class SamplingEngine:
 
         x, x2 = ws['x'], ws['x2']
         cur = 0
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(S + 2)] if getattr(self, 'profile_scales', False) else None
         for si, pn in enumerate(var.patch_nums):                          # var.py:160
             l = pn * pn
             M = B2 * l
+            if ev: ev[si].record()
             for bi, blk in enumerate(w['blocks']):                        # AdaLNSelfAttn.forward, basic_var.py:152-159
                 self.block(blk, ws, bi, x, x2, B2, l, cur)
             cur += l
@@ -611,9 +661,7 @@ class SamplingEngine:
                 if trace: tr['logits'].append(None); tr['idx'].append(idx.view(B, l).clone())
             else:
                 # get_logits (var.py:118-124): AdaLNBeforeHead + head
-                hn = ws['hn']
-                hip.call('ln_modulate_f32', x, hn, 2 * C, hn[:, C:], 2 * C, ws['xn'], M, C, l, var.norm_eps)
-                self.gemm(ws['xn'], w['head_w'], w['head_b'], ws['logits'], M)
+                self.head(x, ws['hn'], ws['xn'], ws['logits'], M, l)
                 if trace: tr['logits'].append(ws['logits'][:M].view(B2, l, V).clone())
                 t = cfg * (si / var.num_stages_minus_1) if var.num_stages_minus_1 > 0 else 0.0
                 idx = ws['idx'][:B * l]
@@ -664,7 +712,12 @@ class SamplingEngine:
         self.last_smooth = (sm_ll, sm_dl) if sm_gt is not None else None
         if not decode:
             return ws['f_hat'].permute(0, 3, 1, 2).contiguous()
-        return self.dec.decode_nhwc(ws['f_hat'])                          # var.py:190
+        if ev: ev[S].record()
+        img = self.dec.decode_nhwc(ws['f_hat'])                           # var.py:190
+        if ev:                                                            # tools/per_scale.py: ms per scale (blocks + head + sampler + quantizer step), then the decoder
+            ev[S + 1].record(); torch.cuda.synchronize()
+            self.last_scale_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(S + 1)]
+        return img
 
     # -- teacher-forced logits (VAR.forward without autograd) ------------------------------------------------------------
     @torch.no_grad()
@@ -685,14 +738,15 @@ class SamplingEngine:
         hid = var.blocks[0].ffn.fc1.weight.shape[0]
         ws = self._ws_tf.get(R) if hasattr(self, '_ws_tf') else None
         if ws is None or ws['dev'] != dev:
-            e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+            e = lambda *s, dt=torch.float32: torch.empty(*s, dtype=dt, device=dev)
+            act = torch.float16 if self.precision == 'f16' else torch.float32
             M = R * lmax
             # x is written by first_map_f32 / word_embed_f32, which also emit the CFG copy of every row (unused here): room for 2x
-            ws = dict(dev=dev, x=e(2 * M, C), x2=e(M, C), xn=e(M, C), q=e(M, C), att=e(M, C), hid=e(M, hid), lg=e(R * lmax, V),
+            ws = dict(dev=dev, x=e(2 * M, C), x2=e(M, C), xn=e(M, C, dt=act), q=e(M, C, dt=act), att=e(M, C, dt=act), hid=e(M, hid, dt=act), lg=e(R * lmax, V),
                       lvl_pos=e(L, C), cond=e(2 * R, C), cond_silu=e(2 * R, C), hn=e(R, 2 * C), ada=e(var.depth, R, 6 * C),
                       shared=e(R, 6 * C) if var.shared_aln else None,
-                      kc=[torch.zeros(R, H, L, 64, dtype=torch.float32, device=dev) for _ in range(var.depth)],
-                      vc=[torch.zeros(R, H, L, 64, dtype=torch.float32, device=dev) for _ in range(var.depth)])
+                      kc=[torch.zeros(R, H, L, 64, dtype=act, device=dev) for _ in range(var.depth)],
+                      vc=[torch.zeros(R, H, L, 64, dtype=act, device=dev) for _ in range(var.depth)])
             self._ws_tf = {R: ws}
         lab = label_B.to(dev).long().contiguous()
         hip.call('lvl_pos_f32', w['lvl_embed'], w['lvl_1L'], w['pos_1LC'], ws['lvl_pos'], L, C)
@@ -718,9 +772,7 @@ class SamplingEngine:
                 hip.call('word_embed_f32', seg, w['word_w'], w['word_b'], ws['lvl_pos'][cur:], x, R, l, C, Cv)
             for bi, blk in enumerate(w['blocks']):
                 self.block(blk, ws, bi, x, x2, R, l, cur)
-            hn = ws['hn']
-            hip.call('ln_modulate_f32', x, hn, 2 * C, hn[:, C:], 2 * C, ws['xn'], M, C, l, var.norm_eps)
-            self.gemm(ws['xn'], w['head_w'], w['head_b'], ws['lg'], M)
+            self.head(x, ws['hn'], ws['xn'], ws['lg'], M, l)
             out[:, cur:cur + l] = ws['lg'][:M].view(R, l, V)
             cur += l
         return out

@@ -82,6 +82,14 @@ class VAR(nn.Module):
             self._engine = SamplingEngine(self)
         return self._engine
 
+    def set_hip_precision(self, precision: str = 'f32'):
+        """'f32' (default: tokens bit-identical to the CPU oracle, pixels within 1e-3 of the reference) or 'f16': fp16 weights / GEMM
+        operands / KV cache with fp32 accumulation — the arithmetic the reference's harness requests through
+        torch.autocast('cuda', dtype=torch.float16) (demo_sample.py:66-68), here selected explicitly (an enclosing autocast context does
+        not change the result of either mode)."""
+        self.engine().set_precision(precision)
+        return self
+
     @torch.no_grad()
     def autoregressive_infer_cfg(self, B: int, label_B: Optional[Union[int, torch.LongTensor]], g_seed: Optional[int] = None, cfg=1.5,
                                  top_k=0, top_p=0.0, more_smooth=False) -> torch.Tensor:
