@@ -289,6 +289,22 @@ int varhip_adaln_block_f16(float* x, float* x2, void* xn16, void* q16, void* att
                            const void* fc2_w16, const float* fc2_b, void* kcache16, void* vcache16,
                            int B2, int l, int C, int H, int hidden, int pos0, int Lmax, float eps, varhip_stream_t stream);
 
+/* the decoder's convolutions in this mode (basic_vae.py:22-28,40-60,163-226 under fp16 autocast): fp16 channels-last activations and
+ * weights ([Cout][3][3][Cin], or the phase form of varhip_upconv_pack_f32 rounded to fp16), fp32 bias, fp16 residual and output;
+ * out_mode 1 / 2: the last conv writes fp32 NCHW, de-normalised to [0,1] / clamped to [-1,1].  gn_part (nullable): per-block
+ * per-channel (sum, sum of squares) of the ROUNDED result, as varhip_conv3x3_gn_nhwc_f32.  Cin % 32 == 0. */
+int varhip_conv3x3_nhwc_f16(const void* in, const void* w, const float* bias, const void* resid, void* out, double* gn_part,
+                            int B, int H, int W, int Cin, int Cout, int out_mode, varhip_stream_t stream);
+int varhip_upconv_phase_f16(const void* in, const void* w_phase, const float* bias, void* out, double* gn_part,
+                            int B, int H, int W, int Cin, int Cout, varhip_stream_t stream);
+/* GroupNorm on fp16 [B][HW][C] (basic_vae.py:18-19): statistics in fp64, affine + optional SiLU in fp32, fp16 result */
+int varhip_gn_stats_f16(const void* x, float* stats, double* scratch, int B, int HW, int C, int G, float eps, varhip_stream_t stream);
+int varhip_gn_apply_f16(const void* x, const float* stats, const float* gamma, const float* beta, void* out,
+                        int B, int HW, int C, int G, int silu, varhip_stream_t stream);
+/* casts at the edges of the mode (n % 4 == 0, 16-byte aligned) */
+int varhip_cast_f32_to_f16(const float* in, void* out, int64_t n, varhip_stream_t stream);
+int varhip_cast_f16_to_f32(const void* in, float* out, int64_t n, varhip_stream_t stream);
+
 /* ---- per-kernel timing (bench.py's roofline leg) -----------------------------------------------------------
  * When enabled, every launch is bracketed by hipEvents on its own stream and its algorithmic FLOPs and bytes are
  * accumulated per kernel family.  varhip_timing_read synchronises the recorded events.

@@ -111,6 +111,114 @@ def test_attn16_against_twin(B2, l, H, curL):
     assert np.abs(got - ref).max() <= 1e-2
 
 
+@pytest.mark.parametrize('B,H,W,Cin,Cout,res,omode', [(2, 16, 16, 32, 32, 0, 0), (2, 16, 16, 640, 640, 1, 0), (1, 32, 32, 320, 160, 0, 0), (3, 8, 8, 160, 160, 1, 0),
+                                                      (2, 32, 32, 160, 3, 0, 1), (1, 16, 16, 64, 3, 0, 2), (1, 24, 40, 96, 64, 1, 0)])
+def test_conv16_against_float64(B, H, W, Cin, Cout, res, omode):
+    hip = _hip()
+    g = torch.Generator().manual_seed(H * 31 + Cin + Cout)
+    x = torch.randn(B, H, W, Cin, generator=g).half()
+    w = (torch.randn(Cout, 3, 3, Cin, generator=g) * (1.0 / (9 * Cin) ** 0.5)).half()
+    bias = torch.randn(Cout, generator=g) * 0.1
+    resid = torch.randn(B, H, W, Cout, generator=g).half() if res else None
+    ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), bias.double(), padding=1)     # NCHW
+    if res: ref = ref + resid.double().permute(0, 3, 1, 2)
+    nblk = hip.conv_gn_blocks(H, W, Cout) if (omode == 0 and Cout % 4 == 0) else 0
+    part = torch.zeros(B, nblk, Cout, 2, dtype=torch.float64, device='cuda') if nblk else None
+    if omode:
+        out = torch.empty(B, Cout, H, W, dtype=torch.float32, device='cuda')
+        ref = ref.clamp(-1, 1); ref = (ref + 1) * 0.5 if omode == 1 else ref
+    else:
+        out = torch.empty(B, H, W, Cout, dtype=torch.float16, device='cuda')
+    hip.call('conv3x3_nhwc_f16', x.cuda(), w.cuda(), bias.cuda(), None if resid is None else resid.cuda(), out, part, B, H, W, Cin, Cout, omode)
+    got = out.double().cpu() if omode else out.double().cpu().permute(0, 3, 1, 2)
+    tol = 1e-5 + (0 if omode else ref.abs() * 2.0 ** -10) + 2e-6 * (9 * Cin) ** 0.5
+    err = (got - ref).abs()
+    assert bool((err <= tol).all()), f'max err {float(err.max()):.3e}'
+    if nblk:                                                     # GroupNorm partials: sums of the ROUNDED outputs, per block of 128 pixels
+        o = out.double().cpu().view(B, nblk, 128, Cout)
+        assert torch.allclose(part[..., 0].cpu(), o.sum(2), rtol=1e-12, atol=1e-9) and torch.allclose(part[..., 1].cpu(), (o * o).sum(2), rtol=1e-12, atol=1e-9)
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout', [(2, 16, 16, 64, 32), (1, 32, 32, 320, 320), (2, 64, 32, 160, 160)])
+def test_upconv_phase16_against_float64(B, H, W, Cin, Cout):
+    """Upsample2x (nearest 2x + conv3x3, basic_vae.py:22-28) in its folded four-phase form on fp16 data"""
+    hip = _hip()
+    g = torch.Generator().manual_seed(H + Cin)
+    x = torch.randn(B, H // 2, W // 2, Cin, generator=g).half()
+    w = torch.randn(Cout, 3, 3, Cin, generator=g) * (1.0 / (9 * Cin) ** 0.5)
+    bias = torch.randn(Cout, generator=g) * 0.1
+    wp = torch.empty(4, Cout, 2, 2, Cin, dtype=torch.float32, device='cuda')
+    hip.call('upconv_pack_f32', w.cuda(), wp, Cin, Cout)
+    wp16 = wp.half()
+    nblk = hip.conv_gn_blocks(H, W, Cout, phase=True)
+    part = torch.zeros(B, max(nblk, 1), Cout, 2, dtype=torch.float64, device='cuda')
+    out = torch.empty(B, H, W, Cout, dtype=torch.float16, device='cuda')
+    hip.call('upconv_phase_f16', x.cuda(), wp16, bias.cuda(), out, part if nblk else None, B, H, W, Cin, Cout)
+    # reference: the phase form itself in float64 with the fp16-rounded phase weights
+    xd = x.double().permute(0, 3, 1, 2)
+    ref = torch.empty(B, Cout, H, W, dtype=torch.float64)
+    for py in range(2):
+        for px in range(2):
+            k = wp16[py * 2 + px].double().cpu().permute(0, 3, 1, 2)                 # [Cout][Cin][2][2]
+            xp = torch.nn.functional.pad(xd, (1 - px, px, 1 - py, py))                # taps (a, b) read low-res pixel (y + a - 1 + py, x + b - 1 + px)
+            ref[:, :, py::2, px::2] = torch.nn.functional.conv2d(xp, k, bias.double())
+    got = out.double().cpu().permute(0, 3, 1, 2)
+    err = (got - ref).abs()
+    assert bool((err <= 1e-5 + ref.abs() * 2.0 ** -10 + 2e-6 * (4 * Cin) ** 0.5).all()), f'max err {float(err.max()):.3e}'
+    # and against the definition (nearest 2x then 3x3 conv) with the unrounded weights: fp16 rounding of the folded weights only
+    ref2 = torch.nn.functional.conv2d(torch.nn.functional.interpolate(xd, scale_factor=2, mode='nearest'), w.double().permute(0, 3, 1, 2), bias.double(), padding=1)
+    assert float((got - ref2).abs().max()) <= 2e-2
+    if nblk:
+        o = out.double().cpu()
+        assert torch.allclose(part[..., 0].sum(1).cpu(), o.sum((1, 2)), rtol=1e-10) and torch.allclose(part[..., 1].sum(1).cpu(), (o * o).sum((1, 2)), rtol=1e-10)
+
+
+@pytest.mark.parametrize('B,HW,C,silu', [(2, 256, 640, 1), (3, 1024, 160, 1), (1, 100, 32, 0), (2, 4096, 320, 1)])
+def test_groupnorm16_against_float64(B, HW, C, silu):
+    hip = _hip()
+    g = torch.Generator().manual_seed(HW + C)
+    x = (torch.randn(B, HW, C, generator=g) * 1.7 + 0.3).half()
+    gamma, beta = torch.randn(C, generator=g) * 0.2 + 1.0, torch.randn(C, generator=g) * 0.2
+    stats = torch.empty(B, 32, 2, dtype=torch.float32, device='cuda')
+    scratch = torch.empty(hip.gn_scratch_elems(B, HW, C, 32), dtype=torch.float64, device='cuda')
+    hip.call('gn_stats_f16', x.cuda(), stats, scratch, B, HW, C, 32, 1e-6)
+    xd = x.double().view(B, HW, 32, C // 32)
+    mean = xd.mean(dim=(1, 3)); var = xd.var(dim=(1, 3), unbiased=False)
+    assert torch.allclose(stats[..., 0].double().cpu(), mean, atol=1e-6) and torch.allclose(stats[..., 1].double().cpu(), (var + 1e-6).rsqrt(), rtol=1e-6)
+    out = torch.empty(B, HW, C, dtype=torch.float16, device='cuda')
+    hip.call('gn_apply_f16', x.cuda(), stats, gamma.cuda(), beta.cuda(), out, B, HW, C, 32, silu)
+    ref = torch.nn.functional.group_norm(x.double().permute(0, 2, 1), 32, gamma.double(), beta.double(), eps=1e-6).permute(0, 2, 1)
+    if silu: ref = torch.nn.functional.silu(ref)
+    err = (out.double().cpu() - ref).abs()
+    assert bool((err <= ref.abs() * 2.0 ** -10 + 1e-3).all()), f'max err {float(err.max()):.3e}'
+    y32 = torch.empty(B, HW, C, dtype=torch.float32, device='cuda')
+    hip.call('cast_f16_to_f32', out, y32, out.numel())
+    back = torch.empty_like(out)
+    hip.call('cast_f32_to_f16', y32, back, out.numel())
+    assert torch.equal(y32, out.float()) and torch.equal(back, out)
+
+
+def test_decoder16_vs_fp32_decoder():
+    """VQVAE.fhat_to_img in the 16-bit mode against the fp32 HIP decoder on the same f_hat (d16-size decoder, 256x256, B=2)"""
+    z, meta = util.load_case('d16_full')
+    vae, var = _models(meta)
+    g = torch.Generator().manual_seed(3)
+    f_hat = (torch.randn(2, 32, 16, 16, generator=g) * 1.5).cuda()
+    with torch.inference_mode():
+        a = vae.fhat_to_img(f_hat).clone()
+        vae._decoder_engine().set_precision('f16')
+        try:
+            b = vae.fhat_to_img(f_hat).clone()
+            b2 = vae.fhat_to_img(f_hat)
+        finally:
+            vae._decoder_engine().set_precision('f32')
+        c = vae.fhat_to_img(f_hat)
+    assert torch.equal(b, b2) and torch.equal(a, c)
+    d = (a - b).abs()
+    print(f'decoder f16 vs f32: max |d| {float(d.max()):.3e}, mean |d| {float(d.mean()):.3e} (range [-1, 1])')
+    assert float(d.max()) <= 5e-2 and float(d.mean()) <= 4e-3 and torch.isfinite(b).all()
+
+
 _MODELS = {}
 
 
@@ -164,7 +272,9 @@ def test_f16_mode_vs_twin_and_reference(name):
     idx = np.concatenate(tr['idx'], axis=1)
     agree_tf = float((idx == z['idx']).mean()); agree_twin = float((idx == r['idx']).mean()); agree_free = float((idx_free == z['idx']).mean())
     msgs.append(f'{name}: token agreement with the fp32 reference, teacher-forced {agree_tf:.3f}, free-running {agree_free:.3f}; with the twin (teacher-forced) {agree_twin:.3f}')
-    ok, m = util.diff_report(f'{name} f16 image (teacher-forced tokens) vs reference', img, z['img'], atol=1e-3); ok_all &= ok; msgs.append(m)
+    # pixels: fp16 activations through the ~50 layers of the decoder (statistics / accumulation in fp32): stated tolerance 2e-2 of the [0,1] range
+    ok, m = util.diff_report(f'{name} f16 image (teacher-forced tokens) vs reference', img, z['img'], atol=2e-2); ok_all &= ok; msgs.append(m)
+    msgs.append(f'{name}: image mean |d| vs reference {float(np.abs(img - z["img"]).mean()):.2e}')
     print('\n'.join(msgs))
     assert ok_all, '\n'.join(msgs)
     assert agree_tf >= 0.9 and agree_twin >= 0.95, msgs[-2]
@@ -187,8 +297,10 @@ def test_f16_mode_properties_d16_full():
         ia = torch.cat(eng.last_trace['idx'], dim=1)
         b = eng.sample(B, labels, None, 1.5, 900, 0.96, noises=noise, trace=True)
         assert torch.equal(a, b) and torch.equal(ia, torch.cat(eng.last_trace['idx'], dim=1))
-        sub = eng.sample(2, labels[1:3], None, 1.5, 900, 0.96, noises=[n.view(B, -1, V)[1:3].reshape(-1, V) for n in noise])
-        assert torch.equal(sub, a[1:3])
+        sub = eng.sample(2, labels[1:3], None, 1.5, 900, 0.96, noises=[n.view(B, -1, V)[1:3].reshape(-1, V) for n in noise], trace=True)
+        assert torch.equal(torch.cat(eng.last_trace['idx'], dim=1), ia[1:3]), 'tokens must not depend on the batch neighbours'
+        # (pixels: the decoder's GroupNorm statistics pass splits its fp64 partial sums by the batch size at 256x256: last-bit differences)
+        assert float((sub - a[1:3]).abs().max()) <= 1e-5
         assert torch.isfinite(a).all() and float(a.min()) >= 0 and float(a.max()) <= 1
     finally:
         var.set_hip_precision('f32')

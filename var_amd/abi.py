@@ -59,6 +59,12 @@ SIGNATURES_F16 = {
     'attn_cached_f16':   [P, P, P, P, I, I, I, I, I],
     'ln_modulate_f16out': [P, P, L, P, L, P, I, I, I, F],
     'adaln_block_f16':   [P, P, P, P, P, P, P, L, P, P, P, F, I, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, F],
+    'conv3x3_nhwc_f16':  [P, P, P, P, P, P, I, I, I, I, I, I],
+    'upconv_phase_f16':  [P, P, P, P, P, I, I, I, I, I],
+    'gn_stats_f16':      [P, P, P, I, I, I, I, F],
+    'gn_apply_f16':      [P, P, P, P, P, I, I, I, I, I],
+    'cast_f32_to_f16':   [P, P, L],
+    'cast_f16_to_f32':   [P, P, L],
 }
 
 EPI_NONE, EPI_GELU, EPI_RESID = 0, 1, 2

@@ -1,0 +1,284 @@
+// conv16.hip — the VQVAE decoder's 3x3 convolutions in the 16-bit throughput mode: channels-last fp16 activations and weights, fp32
+// accumulation on v_mfma_f32_16x16x32_f16, implicit GEMM (reference basic_vae.py:22-28,40-60,163-226 under the harness' fp16 autocast).
+// Not part of the fp32 parity contract (see gemm16.hip); the decoder is off the token path in either mode.
+//
+// Same scheme as the CONV instantiations of k_dma_gemm (gemm.hip): 128 output pixels x (32*TNW) output channels per workgroup, the
+// input tile read through a buffer descriptor whose window starts one row + one pixel before the first sample the tile touches (a padded
+// tap ORs bit 31 into the lane offset: the hardware bounds check writes zeros), weights [Cout][tap][Cin], K order = 32-channel chunk
+// outermost, then tap (the taps of a chunk re-read the same cache lines), Upsample2x as four 2x2 phase convolutions.
+// Differences forced by the 16x rate of the matrix pipe: a K tile is ONE 32-channel chunk of one tap = 64 bytes per row = one MFMA
+// k-step, so the LDS pipeline is NST stages deep with counted s_waitcnt vmcnt (a tile's 20 MFMAs per wave are over in ~320 cycles,
+// far less than one memory latency).  LDS rows of 64 bytes: slot c of row r holds chunk c ^ ((-(r >> 2)) & 3) (conflict-free b128 reads).
+#include "common.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+struct Conv16P {
+    const _Float16* in; const _Float16* w; const float* bias; void* out; const _Float16* resid; double* gn_part;
+    int M, N, K;                   // pixels (of the low-res map in the phase mode), Cout, taps * Cin
+    int H, Wd, Cin, phase, out_mode;     // H, Wd: the map the M pixels live on; phase: Upsample2x phase form (grid.z = 4 phases)
+    int64_t sW;                    // element stride between the phase weight sets
+    int tilesM, tilesN;
+};
+
+__device__ __forceinline__ void vh16c_dma_glob(const void* base, uint32_t voff, uint32_t lds) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(base), "s"(lds) : "memory", "m0");
+}
+__device__ __forceinline__ void vh16c_dma_buf(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff, uint32_t lds) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                 : : "v"(voff), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane(soff)), "s"(__builtin_amdgcn_readfirstlane(lds)) : "memory", "m0");
+}
+template <int N> __device__ __forceinline__ void vh16c_waitcnt_barrier() { asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory"); }
+template <int MAXA, int PER> __device__ __forceinline__ void vh16c_wait_dma_and_barrier(int ahead) {      // `ahead` is wave-uniform
+    if constexpr (MAXA == 0) vh16c_waitcnt_barrier<0>();
+    else { if (ahead >= MAXA) vh16c_waitcnt_barrier<MAXA * PER>(); else vh16c_wait_dma_and_barrier<MAXA - 1, PER>(ahead); }
+}
+
+template <int TNW, int NST>
+__global__ void __launch_bounds__(256, 2) k_conv16(Conv16P p) {
+    constexpr int TMW = 4, BM = 128, BN = TNW * 32, ROWB = 64;
+    constexpr int NIA = 2, NIB = (BN + 63) / 64;                  // DMA instructions (16 rows x 64 B) per wave and K tile
+    constexpr int BROWS = NIB * 64, STAGE = (BM + BROWS) * ROWB, PER = NIA + NIB;
+    static_assert((NST - 2) * PER <= 63, "vmcnt is a 6-bit counter");
+    extern __shared__ __attribute__((aligned(16))) char smc[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int tm_, tn_;
+    {
+        const int nwg = p.tilesM * p.tilesN, bid = blockIdx.x;
+        const int q = nwg >> 3, rem = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        const int lin = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + loc;
+        const int GM = 8, width = GM * p.tilesN, group = lin / width, first = group * GM;
+        const int gsz = (p.tilesM - first) < GM ? (p.tilesM - first) : GM;
+        tm_ = first + (lin % width) % gsz;
+        tn_ = (lin % width) / gsz;
+    }
+    const int m0 = tm_ * BM, n0 = tn_ * BN, bz = blockIdx.z;
+    const int hw = p.H * p.Wd, ntap = p.phase ? 4 : 9;
+    const _Float16* Wb = p.w + (int64_t)bz * p.sW;
+
+    // input window of this workgroup's buffer descriptor: from one row + one pixel before the first sample the tile touches
+    const int mlast = (m0 + BM - 1 < p.M ? m0 + BM - 1 : p.M - 1), mfirst = m0 < p.M ? m0 : p.M - 1;
+    const int cv_b0 = mfirst / hw;
+    const int64_t sample = (int64_t)hw * p.Cin, shift = (int64_t)(p.Wd + 1) * p.Cin;
+    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + (int64_t)cv_b0 * sample - shift), 0,
+                                                                            (int)((((int64_t)(mlast / hw - cv_b0 + 1)) * sample + shift) * 2), 0x00020000);
+    const int drow = lane >> 2, dslot = lane & 3, dchunk = dslot ^ ((-(drow >> 2)) & 3);
+    uint32_t aoff[NIA], abad[NIA], boff[NIB];
+    const int dy0 = p.phase ? (bz >> 1) - 1 : -1, dx0 = p.phase ? (bz & 1) - 1 : -1;
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) {
+        int m = m0 + (wave * NIA + i) * 16 + drow; m = m < p.M ? m : p.M - 1;
+        const int b = m / hw, rem2 = m - b * hw, y = rem2 / p.Wd, x = rem2 - y * p.Wd;
+        aoff[i] = (uint32_t)(((((int64_t)(b - cv_b0) * p.H + y) * p.Wd + x) * p.Cin + dchunk * 8) * 2);
+        const bool r0 = (unsigned)(y + dy0) >= (unsigned)p.H, r1 = (unsigned)(y + dy0 + 1) >= (unsigned)p.H, r2 = (unsigned)(y + dy0 + 2) >= (unsigned)p.H;
+        const bool c0 = (unsigned)(x + dx0) >= (unsigned)p.Wd, c1 = (unsigned)(x + dx0 + 1) >= (unsigned)p.Wd, c2 = (unsigned)(x + dx0 + 2) >= (unsigned)p.Wd;
+        abad[i] = p.phase ? ((r0 ? 0x3u : 0u) | (r1 ? 0xCu : 0u) | (c0 ? 0x5u : 0u) | (c1 ? 0xAu : 0u))
+                          : ((r0 ? 0x007u : 0u) | (r1 ? 0x038u : 0u) | (r2 ? 0x1C0u : 0u) | (c0 ? 0x049u : 0u) | (c1 ? 0x092u : 0u) | (c2 ? 0x124u : 0u));
+    }
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) {
+        int n = n0 + (wave * NIB + i) * 16 + drow; n = n < p.N ? n : p.N - 1;
+        boff[i] = (uint32_t)(((int64_t)n * p.K + dchunk * 8) * 2);
+    }
+    int cv_tap = 0, cv_cc = 0;                                    // tap / channel chunk of the next K tile to be requested (tiles are requested in order)
+    auto dma_tile = [&](int st) {
+        char* sA = smc + st * STAGE + wave * NIA * 16 * ROWB;
+        char* sB = smc + st * STAGE + BM * ROWB + wave * NIB * 16 * ROWB;
+        const int tap = cv_tap, ci0 = cv_cc * 32;
+        if (++cv_tap == ntap) { cv_tap = 0; ++cv_cc; }
+        int dy, dx;
+        if (p.phase) { dy = (tap >> 1) + dy0; dx = (tap & 1) + dx0; }
+        else { const int ky = tap / 3; dy = ky - 1; dx = tap - ky * 3 - 1; }
+        const uint32_t soff = (uint32_t)(((dy + 1) * p.Wd + dx + 1) * p.Cin + ci0) * 2u;
+#pragma unroll
+        for (int i = 0; i < NIA; ++i)
+            vh16c_dma_buf(arsrc, ((abad[i] >> tap) << 31) | aoff[i], soff, (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(sA + i * 16 * ROWB));
+#pragma unroll
+        for (int i = 0; i < NIB; ++i)
+            vh16c_dma_glob((const char*)Wb + (size_t)(tap * p.Cin + ci0) * 2, boff[i], (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(sB + i * 16 * ROWB));
+    };
+
+    f32x4 acc[TMW][TNW];
+#pragma unroll
+    for (int i = 0; i < TMW; ++i)
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int nk = p.K / 32;
+    const int rsl = (kq ^ ((-(r16 >> 2)) & 3)) << 4;              // the lane's 16-byte slot inside a 64-byte LDS row
+    const bool idle_wave = (n0 + wn * TNW * 16 >= p.N) || (m0 + wm * TMW * 16 >= p.M);
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t) if (t < nk) dma_tile(t);
+    if (idle_wave) {                                              // same requests and barriers, no matrix work (kept out of the hot loop)
+        for (int kt = 0; kt < nk; ++kt) {
+            const int ahead = (nk - 1 - kt) < (NST - 2) ? (nk - 1 - kt) : (NST - 2);
+            vh16c_wait_dma_and_barrier<NST - 2, PER>(ahead);
+            if (kt + NST - 1 < nk) dma_tile((kt + NST - 1) % NST);
+        }
+    } else {
+        for (int kt = 0; kt < nk; ++kt) {
+            const int ahead = (nk - 1 - kt) < (NST - 2) ? (nk - 1 - kt) : (NST - 2);
+            vh16c_wait_dma_and_barrier<NST - 2, PER>(ahead);
+            const int cur = kt % NST;
+            const char* sA = smc + cur * STAGE + (wm * TMW * 16 + r16) * ROWB + rsl;
+            const char* sB = smc + cur * STAGE + BM * ROWB + (wn * TNW * 16 + r16) * ROWB + rsl;
+            h8 am[TMW], bn[TNW];
+#pragma unroll
+            for (int i = 0; i < TMW; ++i) am[i] = *(const h8*)(sA + i * 16 * ROWB);
+#pragma unroll
+            for (int j = 0; j < TNW; ++j) bn[j] = *(const h8*)(sB + j * 16 * ROWB);
+            if (kt + NST - 1 < nk) dma_tile((kt + NST - 1) % NST);
+#pragma unroll
+            for (int i = 0; i < TMW; ++i)
+#pragma unroll
+                for (int j = 0; j < TNW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bn[j], am[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();                                              // the stages are free: the GroupNorm partials below reuse them
+
+    // ---- epilogue: acc[i][j][e] = C[pixel m = tile_m(i) + r16][channel n = tile_n(j) + 4*kq + e]
+    const int nw0 = n0 + wn * TNW * 16;
+    const bool vec = !(p.N & 3);
+    if (nw0 < p.N) {
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) {
+            const int n = nw0 + j * 16 + kq * 4;
+            if (n >= p.N) continue;
+            float b4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b4[e] = (n + e < p.N) ? p.bias[n + e] : 0.f;
+            double gs[4] = {0.0, 0.0, 0.0, 0.0}, gq[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int i = 0; i < TMW; ++i) {
+                const int m = m0 + (wm * TMW + i) * 16 + r16;
+                if (m >= p.M) continue;
+                const int b = m / hw, rem2 = m - b * hw;
+                f32x4 v = acc[i][j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] + b4[e];
+                if (p.out_mode != 0) {                                      // last conv: fp32 NCHW store of <= 3 channels, clamp (+ de-normalise)
+                    for (int e = 0; e < 4; ++e) {
+                        if (n + e >= p.N) break;
+                        const float x = vm_min(vm_max(v[e], -1.0f), 1.0f);
+                        ((float*)p.out)[((int64_t)b * p.N + n + e) * hw + rem2] = p.out_mode == 1 ? (x + 1.0f) * 0.5f : x;
+                    }
+                    continue;
+                }
+                int64_t mo = m;                                             // output row; the phase mode scatters to the 2x grid
+                if (p.phase) { const int y = rem2 / p.Wd, x = rem2 - y * p.Wd; mo = ((int64_t)b * (2 * p.H) + 2 * y + (bz >> 1)) * (2 * p.Wd) + 2 * x + (bz & 1); }
+                if (vec) {
+                    if (p.resid) { const h4 r4 = *(const h4*)(p.resid + (int64_t)m * p.N + n);
+#pragma unroll
+                                   for (int e = 0; e < 4; ++e) v[e] = (float)r4[e] + v[e]; }
+                    h4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
+                    *(h4*)((_Float16*)p.out + mo * p.N + n) = o;
+                    if (p.gn_part) {                                        // statistics of what the next GroupNorm will read: the rounded values
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { const double d = (double)(float)o[e]; gs[e] += d; gq[e] += d * d; }
+                    }
+                } else {
+                    for (int e = 0; e < 4; ++e) {
+                        if (n + e >= p.N) break;
+                        float x = v[e];
+                        if (p.resid) x = (float)p.resid[(int64_t)m * p.N + n + e] + x;
+                        ((_Float16*)p.out)[mo * p.N + n + e] = (_Float16)x;
+                    }
+                }
+            }
+            if (p.gn_part) {                                                // host guarantees full tiles and N % 4 == 0
+#pragma unroll
+                for (int off = 8; off >= 1; off >>= 1)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { gs[e] += __shfl_xor(gs[e], off, 64); gq[e] += __shfl_xor(gq[e], off, 64); }
+                if (r16 == 0) {
+                    double* red = reinterpret_cast<double*>(smc);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int nl = (wn * TNW + j) * 16 + kq * 4 + e;
+                        red[(wm * BN + nl) * 2] = gs[e]; red[(wm * BN + nl) * 2 + 1] = gq[e];
+                    }
+                }
+            }
+        }
+    }
+    if (p.gn_part) {
+        __syncthreads();
+        if (tid < BN) {
+            const double* red = reinterpret_cast<const double*>(smc);
+            const double s = red[tid * 2] + red[(BN + tid) * 2], q = red[tid * 2 + 1] + red[(BN + tid) * 2 + 1];
+            const int b = m0 / hw, per = hw / BM, blk = bz * per + (m0 - b * hw) / BM, nblk = (int)gridDim.z * per;
+            double* o = p.gn_part + (((int64_t)b * nblk + blk) * p.N + n0 + tid) * 2;
+            o[0] = s; o[1] = q;
+        }
+    }
+}
+
+template <int TNW, int NST>
+static int launch_conv16(Conv16P& p, int nz, hipStream_t s) {
+    constexpr int BN = TNW * 32, NIB = (BN + 63) / 64;
+    constexpr size_t lds = (size_t)NST * (128 + NIB * 64) * 64;
+    static_assert(lds >= (size_t)2 * BN * 2 * sizeof(double), "GroupNorm partials must fit in the stages");
+    p.tilesM = (p.M + 127) / 128; p.tilesN = (p.N + BN - 1) / BN;
+    auto kfn = k_conv16<TNW, NST>;
+    static bool attr_done = false;
+    if (!attr_done) { if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+    hipLaunchKernelGGL(kfn, dim3(p.tilesM * p.tilesN, 1, nz), dim3(256), lds, s, p);
+    return vh_launch_status();
+}
+static int dispatch_conv16(Conv16P& p, int nz, hipStream_t s) {
+    if (p.N % 160 == 0) return launch_conv16<5, 4>(p, nz, s);
+    if (p.N % 128 == 0) return launch_conv16<4, 4>(p, nz, s);
+    if (p.N % 64 == 0) return launch_conv16<2, 4>(p, nz, s);
+    return launch_conv16<1, 4>(p, nz, s);
+}
+
+static int conv16_checks(const void* in, const void* w, const float* bias, const void* out, int B, int H, int W, int Cin, int Cout) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (Cin & 31) || !bias) return VARHIP_EINVAL;
+    if ((int64_t)B * H * W >= (1ll << 31)) return VARHIP_EINVAL;
+    if ((((uintptr_t)in | (uintptr_t)w | (uintptr_t)out) & 15)) return VARHIP_EINVAL;
+    return 0;
+}
+
+// out = conv3x3(in) + bias (+ resid): in [B][H][W][Cin] fp16, w [Cout][3][3][Cin] fp16, bias fp32, resid / out [B][H][W][Cout] fp16
+// out_mode 1 / 2: the decoder's last conv — fp32 NCHW, clamped to [-1, 1] (2) or de-normalised to [0, 1] (1); gn_part as in gemm.hip
+extern "C" int varhip_conv3x3_nhwc_f16(const void* in, const void* w, const float* bias, const void* resid, void* out, double* gn_part,
+                                       int B, int H, int W, int Cin, int Cout, int out_mode, varhip_stream_t stream) {
+    int rc = conv16_checks(in, w, bias, out, B, H, W, Cin, Cout);
+    if (rc) return rc;
+    if (out_mode < 0 || out_mode > 2 || (out_mode != 0 && (resid || gn_part))) return VARHIP_EINVAL;
+    if (gn_part && (!varhip_conv_gn_blocks(H, W, Cout, 0) || (Cout & 3))) return VARHIP_EINVAL;
+    if ((int64_t)Cout * 9 * Cin * 2 >= (1ll << 32)) return VARHIP_EINVAL;
+    {   const int64_t hw = (int64_t)H * W, sample = hw * Cin;
+        if (((127 / hw + 2) * sample + (int64_t)(W + 1) * Cin) * 2 >= (1ll << 31)) return VARHIP_EINVAL; }
+    Conv16P p{};
+    p.in = (const _Float16*)in; p.w = (const _Float16*)w; p.bias = bias; p.out = out; p.resid = (const _Float16*)resid; p.gn_part = gn_part;
+    p.M = B * H * W; p.N = Cout; p.K = 9 * Cin; p.H = H; p.Wd = W; p.Cin = Cin; p.phase = 0; p.out_mode = out_mode; p.sW = 0;
+    const double npix = (double)B * H * W;
+    VhScope scope((Cout % 160 == 0) ? VH_FAM_CONV : VH_FAM_CONV_SMALL, (hipStream_t)stream, 2.0 * npix * Cout * 9.0 * Cin,
+                  2.0 * (npix * Cin + npix * Cout * (resid ? 2.0 : 1.0) + 9.0 * Cin * Cout));
+    return dispatch_conv16(p, 1, (hipStream_t)stream);
+}
+
+// nearest-2x upsample + conv3x3 as four 2x2 phase convolutions on the low-resolution map: in [B][H/2][W/2][Cin] fp16,
+// w_phase [4][Cout][2][2][Cin] fp16 (varhip_upconv_pack_f32, then rounded to fp16), out [B][H][W][Cout] fp16
+extern "C" int varhip_upconv_phase_f16(const void* in, const void* w_phase, const float* bias, void* out, double* gn_part,
+                                       int B, int H, int W, int Cin, int Cout, varhip_stream_t stream) {
+    int rc = conv16_checks(in, w_phase, bias, out, B, H, W, Cin, Cout);
+    if (rc) return rc;
+    if ((H & 1) || (W & 1) || (Cout & 3)) return VARHIP_EINVAL;
+    if (gn_part && !varhip_conv_gn_blocks(H, W, Cout, 1)) return VARHIP_EINVAL;
+    {   const int64_t hw = (int64_t)(H / 2) * (W / 2), sample = hw * Cin;
+        if (((127 / hw + 2) * sample + (int64_t)(W / 2 + 1) * Cin) * 2 >= (1ll << 31)) return VARHIP_EINVAL; }
+    Conv16P p{};
+    p.in = (const _Float16*)in; p.w = (const _Float16*)w_phase; p.bias = bias; p.out = out; p.resid = nullptr; p.gn_part = gn_part;
+    p.M = B * (H / 2) * (W / 2); p.N = Cout; p.K = 4 * Cin; p.H = H / 2; p.Wd = W / 2; p.Cin = Cin; p.phase = 1; p.out_mode = 0;
+    p.sW = (int64_t)Cout * 4 * Cin;
+    const double npix = (double)B * H * W;
+    VhScope scope((Cout % 160 == 0) ? VH_FAM_CONV : VH_FAM_CONV_SMALL, (hipStream_t)stream, 2.0 * npix * Cout * 4.0 * Cin,
+                  2.0 * (npix * Cin / 4.0 + npix * Cout + 16.0 * Cin * Cout));
+    return dispatch_conv16(p, 4, (hipStream_t)stream);
+}

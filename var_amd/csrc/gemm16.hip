@@ -40,7 +40,7 @@ __device__ __forceinline__ float vh16_gelu(float x) {
 }
 
 template <int TMW, int TNW>
-__global__ void __launch_bounds__(256) k_gemm16(Gemm16P p) {
+__global__ void __launch_bounds__(256, 2) k_gemm16(Gemm16P p) {
     constexpr int BM = TMW * 32, BN = TNW * 32, ROWB = 128, STAGE = (BM + BN) * ROWB;      // bytes
     constexpr int NIA = BM / 32, NIB = BN / 32;                                            // DMA instructions per wave and K tile
     extern __shared__ __attribute__((aligned(16))) char smem16[];

@@ -114,6 +114,14 @@ class DecoderEngine(_VaeOps):
     """VQVAE.fhat_to_img on HIP kernels (reference vqvae.py:62-63, basic_vae.py:163-226)."""
 
     PREFIXES = ('decoder.', 'post_quant_conv.')
+    precision = 'f32'          # 'f16': fp16 activations / conv weights with fp32 accumulation (the 16-bit throughput mode); explicitly selected
+
+    def set_precision(self, precision: str):
+        if precision not in ('f32', 'f16'):
+            raise ValueError("precision must be 'f32' or 'f16'")
+        if precision != self.precision:
+            self.precision = precision
+            self._sig = None
 
     def refresh(self):
         sig = self._signature()
@@ -126,6 +134,10 @@ class DecoderEngine(_VaeOps):
             hip.call('upconv_pack_f32', w[k], wp, cin, cout)
             w[k[:-len('weight')] + 'phase'] = wp
         self.w = w
+        self.w16 = {}
+        if self.precision == 'f16':          # fp16 copies of every conv kernel (3x3, phase, 1x1 shortcut); biases and GroupNorm affine stay fp32
+            self.w16 = {k: v.to(torch.float16).contiguous() for k, v in w.items()
+                        if (k.endswith('.weight') or k.endswith('.phase')) and v.dim() >= 2 and '.attn' not in k}
         self.nlev = 1 + max(int(k.split('.')[2]) for k in w if k.startswith('decoder.up.'))
         self._sig = sig
 
@@ -228,10 +240,87 @@ class DecoderEngine(_VaeOps):
                 f -= 2.0 * hw * co * 5 * ci
         return f
 
+    # -- the 16-bit throughput mode: fp16 activations, conv16.hip / rowops16.hip ----------------------------------------
+    def conv3_16(self, x, key, B, Hh, Ww, resid=None, out_mode=0, stats=False):
+        wt = self.w16[key + '.weight']
+        Cout, Cin = wt.shape[0], wt.shape[3]
+        out = torch.empty((B, Cout, Hh, Ww), dtype=torch.float32, device=x.device) if out_mode else torch.empty((B, Hh, Ww, Cout), dtype=torch.float16, device=x.device)
+        nblk = hip.conv_gn_blocks(Hh, Ww, Cout) if (stats and out_mode == 0 and Cout % 4 == 0) else 0
+        part = self._part_buffer(B, nblk, Cout, x.device) if nblk else None
+        hip.call('conv3x3_nhwc_f16', x, wt, self.w[key + '.bias'], resid, out, part, B, Hh, Ww, Cin, Cout, out_mode)
+        if nblk: self._gn_part = (out, part, nblk)
+        return out
+
+    def gn16(self, x, key, B, HW, silu):
+        Cc = x.shape[-1]
+        stats = torch.empty((B, 32, 2), dtype=torch.float32, device=x.device)
+        pend = self._gn_part
+        self._gn_part = None
+        if pend is not None and pend[0].data_ptr() == x.data_ptr() and pend[0].numel() == x.numel() and tuple(pend[1].shape) == (B, pend[2], Cc, 2):
+            hip.call('gn_stats_part_f32', pend[1], stats, B, pend[2], HW, Cc, 32, 1e-6)
+        else:
+            scratch = torch.empty(hip.gn_scratch_elems(B, HW, Cc, 32), dtype=torch.float64, device=x.device)
+            hip.call('gn_stats_f16', x, stats, scratch, B, HW, Cc, 32, 1e-6)
+        out = torch.empty_like(x)
+        hip.call('gn_apply_f16', x, stats, self.w[key + '.weight'], self.w[key + '.bias'], out, B, HW, Cc, 32, int(silu))
+        return out
+
+    def resblock16(self, x, pre, B, Hh, Ww):
+        HW = Hh * Ww
+        h = self.conv3_16(self.gn16(x, pre + '.norm1', B, HW, True), pre + '.conv1', B, Hh, Ww, stats=True)
+        hn = self.gn16(h, pre + '.norm2', B, HW, True)
+        sc = x
+        if (pre + '.nin_shortcut.weight') in self.w16:              # 1x1 conv == fp16 GEMM over the pixels
+            wt = self.w16[pre + '.nin_shortcut.weight']
+            N, K = wt.shape
+            sc = torch.empty((B, Hh, Ww, N), dtype=torch.float16, device=x.device)
+            hip.call('gemm_nt_f16', x, K, wt, K, self.w[pre + '.nin_shortcut.bias'], sc, N, 1, B * HW, N, K, EPI_NONE, None, 0, 0, None, 0, 1, 1, 0, 0, 0)
+        return self.conv3_16(hn, pre + '.conv2', B, Hh, Ww, resid=sc, stats=True)
+
+    def attnblock16(self, x, pre, B, Hh, Ww):
+        """the four single-head attention blocks at 16x16 (0.5 GMAC each) run in fp32 between two casts"""
+        x32 = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        hip.call('cast_f16_to_f32', x, x32, x.numel())
+        self._gn_part = None
+        y32 = self.attnblock(x32, pre, B, Hh, Ww)
+        y = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+        hip.call('cast_f32_to_f16', y32, y, y.numel())
+        return y
+
+    def _decode16(self, f_hat: torch.Tensor, denorm: bool) -> torch.Tensor:
+        B, P = f_hat.shape[0], f_hat.shape[1]
+        Hh = Ww = P
+        x = torch.empty(f_hat.shape, dtype=torch.float16, device=f_hat.device)
+        hip.call('cast_f32_to_f16', f_hat.contiguous(), x, x.numel())
+        h = self.conv3_16(x, 'post_quant_conv', B, Hh, Ww)
+        h = self.conv3_16(h, 'decoder.conv_in', B, Hh, Ww, stats=True)
+        h = self.resblock16(h, 'decoder.mid.block_1', B, Hh, Ww)
+        h = self.attnblock16(h, 'decoder.mid.attn_1', B, Hh, Ww)
+        h = self.resblock16(h, 'decoder.mid.block_2', B, Hh, Ww)
+        for lev in reversed(range(self.nlev)):
+            for ib in range(3):
+                h = self.resblock16(h, f'decoder.up.{lev}.block.{ib}', B, Hh, Ww)
+                if f'decoder.up.{lev}.attn.{ib}.norm.weight' in self.w:
+                    h = self.attnblock16(h, f'decoder.up.{lev}.attn.{ib}', B, Hh, Ww)
+            if lev != 0:
+                Hh, Ww = 2 * Hh, 2 * Ww
+                key = f'decoder.up.{lev}.upsample.conv'
+                wp = self.w16[key + '.phase']
+                up = torch.empty((B, Hh, Ww, wp.shape[1]), dtype=torch.float16, device=h.device)
+                nblk = hip.conv_gn_blocks(Hh, Ww, wp.shape[1], phase=True)
+                part = self._part_buffer(B, nblk, wp.shape[1], h.device) if nblk else None
+                hip.call('upconv_phase_f16', h, wp, self.w[key + '.bias'], up, part, B, Hh, Ww, wp.shape[4], wp.shape[1])
+                self._gn_part = (up, part, nblk) if nblk else None
+                h = up
+        h = self.gn16(h, 'decoder.norm_out', B, Hh * Ww, True)
+        return self.conv3_16(h, 'decoder.conv_out', B, Hh, Ww, out_mode=1 if denorm else 2)
+
     def decode_nhwc(self, f_hat: torch.Tensor, denorm: bool = True) -> torch.Tensor:
         """[B,P,P,Cvae] channels-last -> [B,3,16P,16P]; denorm=True: in [0,1] (clamp and (x+1)/2 fused into the last conv, what
         autoregressive_infer_cfg returns); denorm=False: clamped to [-1,1] (VQVAE.fhat_to_img's contract)"""
         self.refresh()
+        if self.precision == 'f16':
+            return self._decode16(f_hat, denorm)
         B, P = f_hat.shape[0], f_hat.shape[1]
         Hh = Ww = P
         h = self.conv3(f_hat, 'post_quant_conv', B, Hh, Ww)
@@ -480,6 +569,7 @@ class SamplingEngine:
         (demo_sample.py:66-68).  LayerNorm statistics, AdaLN parameters, the residual stream, softmax, sampler, quantizer and decoder stay fp32."""
         if precision not in ('f32', 'f16'):
             raise ValueError("precision must be 'f32' or 'f16'")
+        self.dec.set_precision(precision)
         if precision != self.precision:
             self.precision = precision
             self._sig = None
