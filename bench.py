@@ -121,12 +121,11 @@ def main():
         flops_img = eng.flops_per_image()
         dec_ref = eng.dec.flops_per_image_reference(pns[-1])        # as the reference computes the decoder (9-tap upsample convs)
         dec_exec = eng.dec.flops_per_image_executed(pns[-1])        # as the kernels execute it (folded 4-tap upsample convs)
-        # the decoder stays fp32 in both modes, so the f16 mode is priced per family: transformer families against the f16 peak
-        fam_peak = {k: (PEAK_F16_MFMA_TFLOPS if (f16 and k in ('gemm', 'gemm_small', 'attn')) else PEAK_F32_MFMA_TFLOPS) for k in MFMA_FAMILIES}
+        fam_peak = {k: (PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS) for k in MFMA_FAMILIES}
         f = tt[dominant]
         achieved = f['flops'] / (f['ms'] * 1e-3) / 1e12 if f['ms'] > 0 else 0.0
         kname = {('gemm', False): 'k_dma_gemm<4,4,false,2,false>', ('conv3x3', False): 'k_dma_gemm<4,5,true,2,false>', ('attn', False): 'k_attn_cached<4>',
-                 ('gemm', True): 'k_gemm16<4,4>', ('conv3x3', True): 'k_dma_gemm<4,5,true,2,false>', ('attn', True): 'k_attn16<4>'}[(dominant, f16)]
+                 ('gemm', True): 'k_gemm16<4,4>', ('conv3x3', True): 'k_conv16<5,4>', ('attn', True): 'k_attn16<4>'}[(dominant, f16)]
         peak = fam_peak[dominant]
         traffic, tsrc = None, None                                   # HBM-side bytes per launch from a separate rocprofv3 --pmc pass of the same config
         for prof in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
@@ -144,7 +143,7 @@ def main():
                  'frac_of_mfma_peak_reference_flops': round(ips * (flops_img + dec_ref) / 1e12 / world / whole_peak, 4),
                  'frac_of_mfma_peak_executed_flops': round(ips * (flops_img + dec_exec) / 1e12 / world / whole_peak, 4),
                  'peak_tflops': whole_peak,
-                 'note': 'ada_lin counted once per call (hoisted; the reference recomputes it per scale); decoder stays fp32 in the f16 mode'}
+                 'note': 'ada_lin counted once per call (hoisted; the reference recomputes it per scale)'}
         table = tt if args.kernel_breakdown else prepass
         if table is not None:
             ms = sum(table[k]['ms'] for k in MFMA_FAMILIES); fl = sum(table[k]['flops'] for k in MFMA_FAMILIES)
@@ -159,7 +158,7 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'VAR-d{args.depth} 256x256 full 10-scale pyramid, CFG=1.5, top_k=900, top_p=0.96, batch={B_local}/GPU, random-init (detinit seed 0)',
                        'global_batch': B_total, 'parallelism': f'dp{world} (batch shard, RCCL all-gather of decoded images)', 'rng_mode': args.rng_mode,
-                       'precision': 'fp32 parity mode' if not f16 else 'fp16 transformer operands / KV cache, fp32 accumulate; fp32 decoder'},
+                       'precision': 'fp32 parity mode' if not f16 else 'fp16 GEMM / conv operands, activations and KV cache, fp32 accumulate and statistics'},
             'roofline': {'bound': 'mfma', 'kernel': kname, 'dominant_by': 'measured (last warmup step)' if prepass is not None else 'profile',
                          'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
                          'traffic': traffic, 'traffic_source': tsrc,

@@ -185,10 +185,12 @@ __global__ void __launch_bounds__(NW * 64, NW) k_attn_cached(const float* __rest
                     if (key >= curL) p[e] = -INFINITY;
                 }
             }
-            float tmax = vh_max3(p[0], p[1], p[2]);
+            // The FIRST read of the score accumulators is compiler-generated code: hipcc pads the MFMA -> VALU read hazard for its own
+            // instructions only, never for an inline-asm consumer (an asm v_max3 placed first read the registers before the last MFMA had
+            // written them: run-to-run differences of the tile maximum).  The asm reads below depend on it, so they stay behind it.
+            float tmax = fmaxf(p[0], p[1]);
 #pragma unroll
-            for (int e = 3; e < 15; e += 2) tmax = vh_max3(tmax, p[e], p[e + 1]);
-            tmax = fmaxf(tmax, p[15]);
+            for (int e = 2; e < 16; e += 2) tmax = vh_max3(tmax, p[e], p[e + 1]);
             {   // both lane halves of a query agree on the tile maximum: after the swap one register holds this half's, the other the other half's
                 auto xr = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
                 const float mnew = vh_max3(mx, __uint_as_float(xr[0]), __uint_as_float(xr[1]));
