@@ -48,6 +48,7 @@ def main():
     ap.add_argument('--dtype', default='f32', choices=['f32', 'f16'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--rng-mode', default='exact', choices=['exact', 'per_rank'])
+    ap.add_argument('--host-init', action='store_true', help='generate the detinit weights with numpy on the host (same bits; keeps the ~8000 tiny init kernels out of a rocprofv3 counter pass)')
     ap.add_argument('--kernel-breakdown', action='store_true',
                     help='time every kernel family with HIP events in the timed region too (adds ~2 %% to a step); default: only the dominant kernel')
     args = ap.parse_args()
@@ -60,7 +61,7 @@ def main():
 
     import torch
     from var_amd import dist, hip
-    from var_amd.detinit import fill_module_device_ as fill_module_      # the detinit values, computed on the GPU (bit-identical to the numpy generator)
+    from var_amd import detinit
     from var_amd.multi import sample_sharded
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -76,6 +77,7 @@ def main():
     pns = (1, 2, 3, 4, 5, 6, 8, 10, 13, 16)
     with contextlib.redirect_stdout(io.StringIO()):
         vae, var = build_vae_var(device=dev, patch_nums=pns, depth=args.depth, ch=160)
+    fill_module_ = detinit.fill_module_ if args.host_init else detinit.fill_module_device_      # identical bits (tests/test_host_cpu.py); the device form takes seconds
     fill_module_(var, args.depth, 0, 'var.'); fill_module_(vae, args.depth, 0, 'vae.')
     var.eval(); vae.eval()
     var.rng = torch.Generator(device=dev)
