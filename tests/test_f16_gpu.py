@@ -55,6 +55,33 @@ def test_gemm16_against_float64(M, N, K, mode):
     assert not bool(bad.any()), f'{mode} {M}x{N}x{K}: {int(bad.sum())} outside tolerance, max err {float((got - ref).abs().max()):.3e}'
 
 
+@pytest.mark.parametrize('tile', [0, 1, 2])
+@pytest.mark.parametrize('M,N,K,mode', [(700, 1024, 256, 'none16'), (513, 520, 128, 'resid32'), (256, 256, 64, 'gelu16'), (1000, 3072, 192, 'none32')])
+def test_gemm16_every_tile_on_ragged_shapes(tile, M, N, K, mode):
+    """the three tile instantiations (128x128, 64x64, 256x256 with 8 waves) forced onto shapes with partial tiles in both dimensions:
+    identical results (same MFMA instruction, same k order), and right against float64"""
+    hip = _hip()
+    g = torch.Generator().manual_seed(M + N)
+    A = (torch.randn(M, K, generator=g) * 0.7).half().cuda(); W = (torch.randn(N, K, generator=g) * (1.5 / K ** 0.5)).half().cuda()
+    bias = (torch.randn(N, generator=g) * 0.2).cuda(); resid = torch.randn(M, N, generator=g).cuda()
+    out16 = mode in ('none16', 'gelu16'); epi = {'none16': 0, 'none32': 0, 'gelu16': 1, 'resid32': 2}[mode]
+    def run(t):
+        out = torch.empty(M, N, dtype=torch.float16 if out16 else torch.float32, device='cuda')
+        hip.lib().so.varhip_gemm16_force_tile(t)
+        try:
+            hip.call('gemm_nt_f16', A, K, W, K, bias, out, N, int(out16), M, N, K, epi, resid if epi == 2 else None, N, 0, None, 0, 1, 1, 0, 0, 0)
+        finally:
+            hip.lib().so.varhip_gemm16_force_tile(-1)
+        return out
+    got, base = run(tile), run(1)
+    assert torch.equal(got, base), f'tile {tile} differs from the 64x64 tile in {int((got != base).sum())} elements'
+    ref = A.double() @ W.double().T + bias.double()
+    if epi == 1: ref = torch.nn.functional.gelu(ref, approximate='tanh')
+    if epi == 2: ref = resid.double() + ref
+    tol = 2e-6 * (A.double().abs() @ W.double().abs().T) + 1e-6 + (ref.abs() * 2.0 ** -10 if out16 else 0) + (1e-6 * ref.abs() if epi == 2 else 0)
+    assert bool(((got.double() - ref).abs() <= tol).all())
+
+
 @pytest.mark.parametrize('B2,l,H,pos0,l2', [(4, 9, 2, 5, 1), (2, 64, 4, 91, 1), (3, 25, 16, 0, 0)])
 def test_gemm_qkv16_against_float64(B2, l, H, pos0, l2):
     hip = _hip()
@@ -67,6 +94,13 @@ def test_gemm_qkv16_against_float64(B2, l, H, pos0, l2):
     q = torch.empty(M, C, dtype=torch.float16, device='cuda')
     kc = torch.zeros(B2, H, Lmax, 64, dtype=torch.float16, device='cuda'); vc = torch.zeros_like(kc)
     hip.call('gemm_qkv_f16', A.cuda(), K, W.cuda(), K, bias.cuda(), M, C, K, smul.cuda(), 0.125, l2, q, kc, vc, B2, l, H, pos0, Lmax)
+    q2 = torch.empty_like(q); kc2 = torch.zeros_like(kc); vc2 = torch.zeros_like(vc)       # the 256x256 tile forced: same bits
+    hip.lib().so.varhip_gemm16_force_tile(2)
+    try:
+        hip.call('gemm_qkv_f16', A.cuda(), K, W.cuda(), K, bias.cuda(), M, C, K, smul.cuda(), 0.125, l2, q2, kc2, vc2, B2, l, H, pos0, Lmax)
+    finally:
+        hip.lib().so.varhip_gemm16_force_tile(-1)
+    assert torch.equal(q, q2) and torch.equal(kc, kc2) and torch.equal(vc, vc2)
     ref = (A.double() @ W.double().T + bias.double()).view(B2, l, 3, H, 64)
     rq, rk, rv = ref[:, :, 0], ref[:, :, 1], ref[:, :, 2]
     if l2:

@@ -115,16 +115,23 @@ def run_gemm16(iters, rounds=3):
         A = torch.randn(M, K, device=dev).half(); W = (torch.randn(N, K, device=dev) * 0.03).half(); b = torch.randn(N, device=dev)
         out16 = torch.empty(M, N, device=dev, dtype=torch.float16); out32 = torch.empty(M, N, device=dev); resid = torch.randn(M, N, device=dev); gamma = torch.randn(128, N, device=dev)
         bufs[name] = (A, W, b, out16, out32, resid, gamma)
+    tiles = [int(t) for t in os.environ.get('GEMM16_TILES', '-1').split(',')]
     for r in range(rounds):
         for name, M, N, K, epi in shapes:
             A, W, b, out16, out32, resid, gamma = bufs[name]
             rpg = max(M // 128, 1)
             o16 = 0 if epi == 2 else 1
             fn = lambda: hip.call('gemm_nt_f16', A, K, W, K, b, out16 if o16 else out32, N, o16, M, N, K, epi, resid if epi == 2 else None, N, 0, gamma if epi == 2 else None, N, rpg, 1, 0, 0, 0)
-            res.setdefault(name, []).append(timeit(fn, iters * 2))
+            for t in tiles:
+                hip.lib().so.varhip_gemm16_force_tile(t)
+                res.setdefault((name, t), []).append(timeit(fn, iters * 2))
+    hip.lib().so.varhip_gemm16_force_tile(-1)
     for name, M, N, K, epi in shapes:
-        ms = min(res[name]); tf = 2.0 * M * N * K / ms / 1e9
-        print(f'gemm16 {name:14s} M={M:6d} N={N:5d} K={K:5d} epi={epi}: {ms*1e3:9.1f} us  {tf:7.1f} TF  {tf/2500*100:5.1f}% of 2.5 PF', flush=True)
+        line = f'gemm16 {name:14s} M={M:6d} N={N:5d} K={K:5d} epi={epi}:'
+        for t in tiles:
+            ms = min(res[(name, t)]); tf = 2.0 * M * N * K / ms / 1e9
+            line += f'  [tile {t:2d}] {ms*1e3:8.1f} us {tf:7.1f} TF ({tf/2500*100:4.1f}%)'
+        print(line, flush=True)
 
 
 def run_attn16(iters):

@@ -39,13 +39,18 @@ __device__ __forceinline__ float vh16_gelu(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
-template <int TMW, int TNW>
-__global__ void __launch_bounds__(256, 2) k_gemm16(Gemm16P p) {
-    constexpr int BM = TMW * 32, BN = TNW * 32, ROWB = 128, STAGE = (BM + BN) * ROWB;      // bytes
-    constexpr int NIA = BM / 32, NIB = BN / 32;                                            // DMA instructions per wave and K tile
+// WM x WN waves, each owning (TMW*16) x (TNW*16) outputs.  2x2 waves: 128x128 / 64x128 / 64x64 tiles, two workgroups per CU.
+// 2x4 waves with TMW = 8, TNW = 4: the 256x256 tile (one workgroup of 8 waves per CU, 128 KB of LDS): a K tile step then moves 64 KB
+// for 8.4 MFLOP = 128 FLOP per L2->LDS byte, twice the 128x128 tile's — at the f16 MFMA rate the smaller tile is bound by what the
+// L2s can deliver.
+template <int TMW, int TNW, int WM = 2, int WN = 2>
+__global__ void __launch_bounds__(64 * WM * WN, 2) k_gemm16(Gemm16P p) {
+    constexpr int NWAVE = WM * WN, BM = TMW * 16 * WM, BN = TNW * 16 * WN, ROWB = 128, STAGE = (BM + BN) * ROWB;      // bytes
+    constexpr int NIA = BM / NWAVE / 8, NIB = BN / NWAVE / 8;                              // DMA instructions (8 rows x 128 B) per wave and K tile
+    static_assert(BM % (NWAVE * 8) == 0 && BN % (NWAVE * 8) == 0, "tile rows must split evenly over the waves' DMA instructions");
     extern __shared__ __attribute__((aligned(16))) char smem16[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     int tm_, tn_;
     {   // XCD-contiguous, grouped block order (as k_dma_gemm)
         const int nwg = p.tilesM * p.tilesN, bid = blockIdx.x;
@@ -64,17 +69,17 @@ __global__ void __launch_bounds__(256, 2) k_gemm16(Gemm16P p) {
     uint32_t aoff[NIA], boff[NIB];
 #pragma unroll
     for (int i = 0; i < NIA; ++i) {
-        int m = m0 + wave * (BM / 4) + i * 8 + drow; m = m < p.M ? m : p.M - 1;
+        int m = m0 + wave * (BM / NWAVE) + i * 8 + drow; m = m < p.M ? m : p.M - 1;
         aoff[i] = (uint32_t)((int64_t)m * p.lda * 2 + ((dslot ^ drow) << 4));
     }
 #pragma unroll
     for (int i = 0; i < NIB; ++i) {
-        int n = n0 + wave * (BN / 4) + i * 8 + drow; n = n < p.N ? n : p.N - 1;
+        int n = n0 + wave * (BN / NWAVE) + i * 8 + drow; n = n < p.N ? n : p.N - 1;
         boff[i] = (uint32_t)((int64_t)n * p.ldw * 2 + ((dslot ^ drow) << 4));
     }
     auto dma_tile = [&](int kt, int st) {
-        char* sA = smem16 + st * STAGE + wave * (BM / 4) * ROWB;
-        char* sB = smem16 + st * STAGE + BM * ROWB + wave * (BN / 4) * ROWB;
+        char* sA = smem16 + st * STAGE + wave * (BM / NWAVE) * ROWB;
+        char* sB = smem16 + st * STAGE + BM * ROWB + wave * (BN / NWAVE) * ROWB;
 #pragma unroll
         for (int i = 0; i < NIA; ++i)
             vh16_dma16(Ab + (size_t)kt * ROWB, aoff[i], (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(sA + i * 8 * ROWB));
@@ -95,22 +100,46 @@ __global__ void __launch_bounds__(256, 2) k_gemm16(Gemm16P p) {
     auto compute = [&](int cur, auto&& mid) {
         const char* sA = smem16 + cur * STAGE + (wm * TMW * 16 + r16) * ROWB;
         const char* sB = smem16 + cur * STAGE + BM * ROWB + (wn * TNW * 16 + r16) * ROWB;
-        h8 am[2][TMW], bn[2][TNW];
+        if constexpr (TMW * TNW <= 16) {
+            // small wave tile: the fragments of both k-steps are fetched up front (32 registers at 4x4)
+            h8 am[2][TMW], bn[2][TNW];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int sl = ((4 * s + kq) ^ (r16 & 7)) << 4;          // rows i*16 + r16: (row & 7) == (r16 & 7)
+            for (int s = 0; s < 2; ++s) {
+                const int sl = ((4 * s + kq) ^ (r16 & 7)) << 4;          // rows i*16 + r16: (row & 7) == (r16 & 7)
 #pragma unroll
-            for (int i = 0; i < TMW; ++i) am[s][i] = *(const h8*)(sA + i * 16 * ROWB + sl);
+                for (int i = 0; i < TMW; ++i) am[s][i] = *(const h8*)(sA + i * 16 * ROWB + sl);
 #pragma unroll
-            for (int j = 0; j < TNW; ++j) bn[s][j] = *(const h8*)(sB + j * 16 * ROWB + sl);
-        }
+                for (int j = 0; j < TNW; ++j) bn[s][j] = *(const h8*)(sB + j * 16 * ROWB + sl);
+            }
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+            for (int s = 0; s < 2; ++s) {
 #pragma unroll
-            for (int i = 0; i < TMW; ++i)
+                for (int i = 0; i < TMW; ++i)
 #pragma unroll
-                for (int j = 0; j < TNW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bn[s][j], am[s][i], acc[i][j], 0, 0, 0);
-            if (s == 0) mid();
+                    for (int j = 0; j < TNW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bn[s][j], am[s][i], acc[i][j], 0, 0, 0);
+                if (s == 0) mid();
+            }
+        } else {
+            // 8x4 wave tile (128 accumulator registers): one k-step's fragments at a time; the weight fragments of step 1 are fetched
+            // while the MFMAs of step 0 run, the activation fragments half a step ahead (register budget: 256 at two waves per SIMD)
+            h8 bn[2][TNW], am[TMW];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int sl = ((4 * s + kq) ^ (r16 & 7)) << 4;
+#pragma unroll
+                for (int j = 0; j < TNW; ++j) bn[s][j] = *(const h8*)(sB + j * 16 * ROWB + sl);
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int sl = ((4 * s + kq) ^ (r16 & 7)) << 4;
+#pragma unroll
+                for (int i = 0; i < TMW; ++i) am[i] = *(const h8*)(sA + i * 16 * ROWB + sl);
+#pragma unroll
+                for (int i = 0; i < TMW; ++i)
+#pragma unroll
+                    for (int j = 0; j < TNW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bn[s][j], am[i], acc[i][j], 0, 0, 0);
+                if (s == 0) mid();
+            }
         }
     };
     dma_tile(0, 0);
@@ -202,22 +231,29 @@ __global__ void __launch_bounds__(256, 2) k_gemm16(Gemm16P p) {
     }
 }
 
-template <int TMW, int TNW>
+template <int TMW, int TNW, int WM = 2, int WN = 2>
 static int launch16(Gemm16P& p, int batch, hipStream_t stream) {
-    constexpr int BM = TMW * 32, BN = TNW * 32;
+    constexpr int BM = TMW * 16 * WM, BN = TNW * 16 * WN;
     constexpr size_t lds = 2 * (size_t)(BM + BN) * 128;
     p.tilesM = (p.M + BM - 1) / BM; p.tilesN = (p.N + BN - 1) / BN;
-    auto kfn = k_gemm16<TMW, TNW>;
+    auto kfn = k_gemm16<TMW, TNW, WM, WN>;
     static bool attr_done = false;
     if (!attr_done) { if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
-    hipLaunchKernelGGL(kfn, dim3(p.tilesM * p.tilesN, 1, batch), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL(kfn, dim3(p.tilesM * p.tilesN, 1, batch), dim3(64 * WM * WN), lds, stream, p);
     return vh_launch_status();
 }
 
+static int g_force_tile16 = -1;
+// testing / experiments: force the tile of the next varhip_gemm_nt_f16 / varhip_gemm_qkv_f16 calls (0: 128x128, 1: 64x64 (64x128 for q/k/v), 2: 256x256, -1: automatic)
+extern "C" int varhip_gemm16_force_tile(int tile) { g_force_tile16 = (tile >= 0 && tile <= 2) ? tile : -1; return 0; }
+
 static int pick_tile16(int M, int N, int batch) {
-    // 128x128 when it fills the chip at least twice over, else 64x64 (K cannot be split without a reduction pass; the small scales are
-    // weight-streaming bound anyway)
+    // 256x256 (8 waves, one workgroup per CU) when it gives every CU at least one tile and rounds of 256 lose little; 128x128 when that fills
+    // the chip at least twice over; else 64x64 (K cannot be split without a reduction pass; the small scales are launch-latency bound anyway)
+    if (g_force_tile16 >= 0) return g_force_tile16;
+    const int64_t nb256 = (int64_t)((M + 255) / 256) * ((N + 255) / 256) * batch;
     const int64_t nb128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128) * batch;
+    if (nb256 >= 256 && (double)nb256 / (double)(((nb256 + 255) / 256) * 256) >= 0.8) return 2;
     return nb128 >= 512 ? 0 : 1;
 }
 
@@ -237,8 +273,9 @@ extern "C" int varhip_gemm_nt_f16(const void* A, int64_t lda, const void* W, int
     p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.ldr = ldr; p.ldg = ldg; p.sA = sA; p.sW = sW; p.sO = sO;
     p.M = M; p.N = N; p.K = K; p.epi = epi; p.rows_per_group = rows_per_group > 0 ? rows_per_group : 1; p.out_f16 = out_f16; p.resid_f16 = resid_f16;
     const int pick = pick_tile16(M, N, batch);
-    VhScope scope(pick == 0 ? VH_FAM_GEMM : VH_FAM_GEMM_SMALL, (hipStream_t)stream, 2.0 * M * N * (double)K * batch,
+    VhScope scope(pick == 2 ? VH_FAM_GEMM : VH_FAM_GEMM_SMALL, (hipStream_t)stream, 2.0 * M * N * (double)K * batch,
                   batch * (2.0 * ((double)M * K + (double)N * K) + (out_f16 ? 2.0 : 4.0) * (double)M * N));
+    if (pick == 2) return launch16<8, 4, 2, 4>(p, batch, (hipStream_t)stream);
     return pick == 0 ? launch16<4, 4>(p, batch, (hipStream_t)stream) : launch16<2, 2>(p, batch, (hipStream_t)stream);
 }
 
@@ -255,7 +292,8 @@ extern "C" int varhip_gemm_qkv_f16(const void* A, int64_t lda, const void* W, in
     p.M = M; p.N = 3 * C; p.K = K; p.epi = 3; p.rows_per_group = 1;
     p.q_smul = scale_mul; p.q_out = (_Float16*)q_out; p.q_kc = (_Float16*)kcache; p.q_vc = (_Float16*)vcache; p.q_plain = plain_scale;
     p.q_l2 = l2norm; p.q_l = l; p.q_pos0 = pos0; p.q_Lmax = Lmax;
-    const bool big = (int64_t)((M + 127) / 128) * ((3 * C + 127) / 128) >= 512;
-    VhScope scope(big ? VH_FAM_GEMM : VH_FAM_GEMM_SMALL, (hipStream_t)stream, 2.0 * M * 3.0 * C * (double)K, 2.0 * ((double)M * K + 3.0 * C * K + 3.0 * M * C));
-    return big ? launch16<4, 4>(p, 1, (hipStream_t)stream) : launch16<2, 4>(p, 1, (hipStream_t)stream);
+    const int pick = pick_tile16(M, 3 * C, 1);
+    VhScope scope(pick == 2 ? VH_FAM_GEMM : VH_FAM_GEMM_SMALL, (hipStream_t)stream, 2.0 * M * 3.0 * C * (double)K, 2.0 * ((double)M * K + 3.0 * C * K + 3.0 * M * C));
+    if (pick == 2) return launch16<8, 4, 2, 4>(p, 1, (hipStream_t)stream);
+    return pick == 0 ? launch16<4, 4>(p, 1, (hipStream_t)stream) : launch16<2, 4>(p, 1, (hipStream_t)stream);
 }
