@@ -82,7 +82,7 @@ def test_gemm16_every_tile_on_ragged_shapes(tile, M, N, K, mode):
     assert bool(((got.double() - ref).abs() <= tol).all())
 
 
-@pytest.mark.parametrize('B2,l,H,pos0,l2', [(4, 9, 2, 5, 1), (2, 64, 4, 91, 1), (3, 25, 16, 0, 0)])
+@pytest.mark.parametrize('B2,l,H,pos0,l2', [(4, 9, 2, 5, 1), (2, 64, 4, 91, 1), (3, 25, 16, 0, 0), (4, 100, 4, 10, 1), (6, 50, 8, 3, 0)])
 def test_gemm_qkv16_against_float64(B2, l, H, pos0, l2):
     hip = _hip()
     C, K, Lmax = H * 64, H * 64, 160

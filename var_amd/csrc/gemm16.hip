@@ -158,6 +158,59 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) k_gemm16(Gemm16P p) {
     }
 
     // ---- epilogue: acc[i][j][e] = C[m = tile_m(i) + r16][n = tile_n(j) + 4*kq + e]
+    if constexpr (NWAVE == 8 && TNW == 4) {
+        // Full 256x256 tiles: staged through LDS so that every global access is a whole row of the tile.  Straight from the accumulators a
+        // store instruction touches 16 rows x 64 bytes (32 bytes for fp16 results): at the f16 matrix rate those half- and quarter-line
+        // accesses cost more than the K loop of a K = 1024 GEMM.  Pass i: every wave parks its 16 rows x 64 columns, then wave w takes rows
+        // 4w .. 4w+3 of the 32 parked rows: lane = 4 consecutive columns, so a row is one 1 KiB (fp32) / 512 B (fp16) access.
+        if (m0 + BM <= p.M && n0 + BN <= p.N) {
+            constexpr int SROW = BN * 4 + 64;                          // bytes per parked row: 256 floats + pad (the stages are free: the K loop ended on a barrier)
+            const int n = n0 + lane * 4;
+            const f32x4 b4 = p.bias ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            int sect = 0, head = 0, Cq = 0, Hh = 0; float sm = 1.0f;
+            if (p.epi == 3) { Cq = p.N / 3; sect = n / Cq; head = (n - sect * Cq) >> 6; Hh = Cq >> 6;
+                              sm = (p.q_l2 && sect == 0) ? vm_exp(vm_min(p.q_smul[head], 4.605170249938965f)) : 1.0f; }
+            char* Ob = (char*)p.out + (int64_t)bz * p.sO * (p.out_f16 ? 2 : 4);
+#pragma unroll
+            for (int i = 0; i < TMW; ++i) {
+                char* wr = smem16 + (wm * 16 + r16) * SROW + (wn * 64 + kq * 4) * 4;
+#pragma unroll
+                for (int j = 0; j < TNW; ++j) *(f32x4*)(wr + j * 64) = acc[i][j];
+                __syncthreads();
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int sr = 4 * wave + rr, m = m0 + (sr >> 4) * (TMW * 16) + i * 16 + (sr & 15);
+                    f32x4 v = *(const f32x4*)(smem16 + sr * SROW + lane * 16) + b4;
+                    if (p.epi == 3) {
+                        if (p.q_l2 && sect < 2) {
+                            float ss = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);      // a head = 16 lanes x 4 columns
+#pragma unroll
+                            for (int off = 8; off >= 1; off >>= 1) ss = ss + __shfl_xor(ss, off, 64);
+                            v = v * ((sect == 0 ? sm : 1.0f) / vm_max(vm_sqrt(ss), 1e-12f));
+                        } else if (!p.q_l2 && sect == 0) v = v * p.q_plain;
+                        _Float16* dst;
+                        if (sect == 0) dst = p.q_out + (int64_t)m * Cq + head * 64;
+                        else { const int bb = m / p.q_l, t = m - bb * p.q_l; dst = (sect == 1 ? p.q_kc : p.q_vc) + (((int64_t)bb * Hh + head) * p.q_Lmax + p.q_pos0 + t) * 64; }
+                        h4 o; o[0] = (_Float16)v[0]; o[1] = (_Float16)v[1]; o[2] = (_Float16)v[2]; o[3] = (_Float16)v[3];
+                        *(h4*)(dst + (lane & 15) * 4) = o;
+                        continue;
+                    }
+                    if (p.epi == VARHIP_EPI_GELU) { v[0] = vh16_gelu(v[0]); v[1] = vh16_gelu(v[1]); v[2] = vh16_gelu(v[2]); v[3] = vh16_gelu(v[3]); }
+                    else if (p.epi == VARHIP_EPI_RESID) {
+                        if (p.gamma) v = v * *(const f32x4*)(p.gamma + (int64_t)(m / p.rows_per_group) * p.ldg + n);
+                        if (p.resid_f16) { const h4 r4 = *(const h4*)((const _Float16*)p.resid + (int64_t)m * p.ldr + n);
+                                           v[0] = (float)r4[0] + v[0]; v[1] = (float)r4[1] + v[1]; v[2] = (float)r4[2] + v[2]; v[3] = (float)r4[3] + v[3]; }
+                        else v = *(const f32x4*)((const float*)p.resid + (int64_t)m * p.ldr + n) + v;
+                    }
+                    if (p.out_f16) { h4 o; o[0] = (_Float16)v[0]; o[1] = (_Float16)v[1]; o[2] = (_Float16)v[2]; o[3] = (_Float16)v[3];
+                                     *(h4*)(Ob + ((int64_t)m * p.ldo + n) * 2) = o; }
+                    else *(f32x4*)(Ob + ((int64_t)m * p.ldo + n) * 4) = v;
+                }
+                __syncthreads();
+            }
+            return;
+        }
+    }
     const int nw0 = n0 + wn * TNW * 16;
     if (nw0 >= p.N) return;
     if constexpr (TNW == 4) {
