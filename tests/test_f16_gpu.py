@@ -100,7 +100,7 @@ def test_gemm_qkv16_against_float64(B2, l, H, pos0, l2):
         hip.call('gemm_qkv_f16', A.cuda(), K, W.cuda(), K, bias.cuda(), M, C, K, smul.cuda(), 0.125, l2, q2, kc2, vc2, B2, l, H, pos0, Lmax)
     finally:
         hip.lib().so.varhip_gemm16_force_tile(-1)
-    assert torch.equal(q, q2) and torch.equal(kc, kc2) and torch.equal(vc, vc2)
+    assert torch.equal(vc, vc2)                                   # v rows: no normalisation, identical bits; q / k: the sum of squares is taken in another order
     ref = (A.double() @ W.double().T + bias.double()).view(B2, l, 3, H, 64)
     rq, rk, rv = ref[:, :, 0], ref[:, :, 1], ref[:, :, 2]
     if l2:
@@ -111,9 +111,10 @@ def test_gemm_qkv16_against_float64(B2, l, H, pos0, l2):
     def close(a, b, name):
         err = (a.double().cpu() - b).abs(); tol = b.abs() * 2.0 ** -10 + 2e-4
         assert bool((err <= tol).all()), f'{name}: max err {float(err.max()):.3e}'
-    close(q.view(B2, l, H, 64), rq, 'q')
-    close(kc[:, :, pos0:pos0 + l].permute(0, 2, 1, 3), rk, 'k cache rows')
-    close(vc[:, :, pos0:pos0 + l].permute(0, 2, 1, 3), rv, 'v cache rows')
+    for qq, kk, vv, tag in ((q, kc, vc, 'auto tile'), (q2, kc2, vc2, '256x256 tile')):
+        close(qq.view(B2, l, H, 64), rq, f'q ({tag})')
+        close(kk[:, :, pos0:pos0 + l].permute(0, 2, 1, 3), rk, f'k cache rows ({tag})')
+        close(vv[:, :, pos0:pos0 + l].permute(0, 2, 1, 3), rv, f'v cache rows ({tag})')
     assert float(kc[:, :, :pos0].abs().max() if pos0 else 0) == 0 and float(kc[:, :, pos0 + l:].abs().max()) == 0
 
 
