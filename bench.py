@@ -130,11 +130,11 @@ def main():
                  ('gemm', True): 'k_gemm16<8,4,2,4>', ('conv3x3', True): 'k_conv16<5,4>', ('attn', True): 'k_attn16<4>'}[(dominant, f16)]
         peak = fam_peak[dominant]
         traffic, tsrc = None, None                                   # HBM-side bytes per launch from a separate rocprofv3 --pmc pass of the same config
-        for prof in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+        for prof, pdt in ((f'r02_{args.dtype}_pmc_traffic.json', args.dtype), ('r01_pmc_traffic.json', 'f32')):
             try:
                 pj = json.load(open(os.path.join(ROOT, 'profiles', prof)))
                 pm = pj['kernels'].get(kname)
-                if pm and args.batch == 64 and args.depth == 16 and pj.get('dtype', 'f32') == args.dtype:
+                if pm and args.batch == 64 and args.depth == 16 and pdt == args.dtype:
                     traffic, tsrc = pm['traffic_bytes_per_launch'], f'profiles/{prof} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)'
                     break
             except (OSError, KeyError, ValueError):

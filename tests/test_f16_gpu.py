@@ -147,9 +147,19 @@ def test_attn16_against_twin(B2, l, H, curL):
 
 
 @pytest.mark.parametrize('B,H,W,Cin,Cout,res,omode', [(2, 16, 16, 32, 32, 0, 0), (2, 16, 16, 640, 640, 1, 0), (1, 32, 32, 320, 160, 0, 0), (3, 8, 8, 160, 160, 1, 0),
-                                                      (2, 32, 32, 160, 3, 0, 1), (1, 16, 16, 64, 3, 0, 2), (1, 24, 40, 96, 64, 1, 0)])
-def test_conv16_against_float64(B, H, W, Cin, Cout, res, omode):
+                                                      (2, 32, 32, 160, 3, 0, 1), (1, 16, 16, 64, 3, 0, 2), (1, 24, 40, 96, 64, 1, 0), (1, 24, 16, 64, 128, 1, 0)])
+@pytest.mark.parametrize('wm', [2, 4])
+def test_conv16_against_float64(B, H, W, Cin, Cout, res, omode, wm):
+    """both pixel tiles (128 pixels x 4 waves, 256 pixels x 8 waves), forced: the automatic choice takes the large one only once it fills the chip"""
     hip = _hip()
+    hip.lib().so.varhip_conv16_force_tile(wm)
+    try:
+        _conv16_case(hip, B, H, W, Cin, Cout, res, omode)
+    finally:
+        hip.lib().so.varhip_conv16_force_tile(0)
+
+
+def _conv16_case(hip, B, H, W, Cin, Cout, res, omode):
     g = torch.Generator().manual_seed(H * 31 + Cin + Cout)
     x = torch.randn(B, H, W, Cin, generator=g).half()
     w = (torch.randn(Cout, 3, 3, Cin, generator=g) * (1.0 / (9 * Cin) ** 0.5)).half()
@@ -171,13 +181,23 @@ def test_conv16_against_float64(B, H, W, Cin, Cout, res, omode):
     assert bool((err <= tol).all()), f'max err {float(err.max()):.3e}'
     if nblk:                                                     # GroupNorm partials: sums of the ROUNDED outputs, per block of 128 pixels
         o = out.double().cpu().view(B, nblk, 128, Cout)
-        assert torch.allclose(part[..., 0].cpu(), o.sum(2), rtol=1e-12, atol=1e-9) and torch.allclose(part[..., 1].cpu(), (o * o).sum(2), rtol=1e-12, atol=1e-9)
+        # fp32 inside a wave (<= 16 of the fp16 values per lane, then 64 / PXI lanes), fp64 across waves, blocks and in the statistics kernel
+        assert torch.allclose(part[..., 0].cpu(), o.sum(2), rtol=1e-5, atol=1e-4) and torch.allclose(part[..., 1].cpu(), (o * o).sum(2), rtol=1e-5, atol=1e-4)
 
 
-@pytest.mark.parametrize('B,H,W,Cin,Cout', [(2, 16, 16, 64, 32), (1, 32, 32, 320, 320), (2, 64, 32, 160, 160)])
-def test_upconv_phase16_against_float64(B, H, W, Cin, Cout):
-    """Upsample2x (nearest 2x + conv3x3, basic_vae.py:22-28) in its folded four-phase form on fp16 data"""
+@pytest.mark.parametrize('B,H,W,Cin,Cout', [(2, 16, 16, 64, 32), (1, 32, 32, 320, 320), (2, 64, 32, 160, 160), (3, 48, 16, 32, 128)])
+@pytest.mark.parametrize('wm', [2, 4])
+def test_upconv_phase16_against_float64(B, H, W, Cin, Cout, wm):
+    """Upsample2x (nearest 2x + conv3x3, basic_vae.py:22-28) in its folded four-phase form on fp16 data, both pixel tiles"""
     hip = _hip()
+    hip.lib().so.varhip_conv16_force_tile(wm)
+    try:
+        _upconv16_case(hip, B, H, W, Cin, Cout)
+    finally:
+        hip.lib().so.varhip_conv16_force_tile(0)
+
+
+def _upconv16_case(hip, B, H, W, Cin, Cout):
     g = torch.Generator().manual_seed(H + Cin)
     x = torch.randn(B, H // 2, W // 2, Cin, generator=g).half()
     w = torch.randn(Cout, 3, 3, Cin, generator=g) * (1.0 / (9 * Cin) ** 0.5)
@@ -205,7 +225,7 @@ def test_upconv_phase16_against_float64(B, H, W, Cin, Cout):
     assert float((got - ref2).abs().max()) <= 2e-2
     if nblk:
         o = out.double().cpu()
-        assert torch.allclose(part[..., 0].sum(1).cpu(), o.sum((1, 2)), rtol=1e-10) and torch.allclose(part[..., 1].sum(1).cpu(), (o * o).sum((1, 2)), rtol=1e-10)
+        assert torch.allclose(part[..., 0].sum(1).cpu(), o.sum((1, 2)), rtol=1e-5, atol=1e-3) and torch.allclose(part[..., 1].sum(1).cpu(), (o * o).sum((1, 2)), rtol=1e-5, atol=1e-3)
 
 
 @pytest.mark.parametrize('B,HW,C,silu', [(2, 256, 640, 1), (3, 1024, 160, 1), (1, 100, 32, 0), (2, 4096, 320, 1)])

@@ -134,6 +134,33 @@ def run_gemm16(iters, rounds=3):
         print(line, flush=True)
 
 
+def run_conv16(iters):
+    """the 16-bit mode's decoder convolutions at the d16 / B=64 shapes, both pixel tiles (CONV16_TILES=2,4; 0 = automatic)"""
+    dev = 'cuda'
+    tiles = [int(t) for t in os.environ.get('CONV16_TILES', '2,4').split(',')]
+    for (B, H, W, Cin, Cout, up2, res) in [(64, 256, 256, 160, 160, 0, 1), (64, 256, 256, 160, 160, 1, 0), (64, 128, 128, 320, 160, 0, 0), (64, 128, 128, 160, 160, 0, 1),
+                                           (64, 128, 128, 320, 320, 1, 0), (64, 64, 64, 320, 320, 0, 1), (64, 32, 32, 640, 320, 0, 0), (64, 32, 32, 640, 640, 1, 0), (64, 16, 16, 640, 640, 0, 1)]:
+        Hi, Wi = (H // 2, W // 2) if up2 else (H, W)
+        x = torch.randn(B, Hi, Wi, Cin, device=dev).half(); b = torch.randn(Cout, device=dev)
+        w = (torch.randn(4, Cout, 2, 2, Cin, device=dev) * 0.02).half() if up2 else (torch.randn(Cout, 3, 3, Cin, device=dev) * 0.02).half()
+        r = torch.randn(B, H, W, Cout, device=dev).half() if res else None
+        out = torch.empty(B, H, W, Cout, device=dev, dtype=torch.float16)
+        nblk = hip.conv_gn_blocks(H, W, Cout, phase=bool(up2))
+        part = torch.zeros(B, max(nblk, 1), Cout, 2, dtype=torch.float64, device=dev)
+        if os.environ.get('CONV16_NOGN'): part = None
+        if os.environ.get('CONV16_NORES'): r = None
+        if up2: fn = lambda: hip.call('upconv_phase_f16', x, w, b, out, part, B, H, W, Cin, Cout)
+        else: fn = lambda: hip.call('conv3x3_nhwc_f16', x, w, b, r, out, part, B, H, W, Cin, Cout, 0)
+        line = f'conv16 {Cin:3d}->{Cout:3d} {H:3d}x{W:3d} up{up2} res{res}:'
+        for t in tiles:
+            hip.lib().so.varhip_conv16_force_tile(t)
+            ms = timeit(fn, max(iters // 2, 2)); tf = 2.0 * B * H * W * Cout * (4 if up2 else 9) * Cin / ms / 1e9
+            line += f'  [wm {t}] {ms:8.3f} ms {tf:7.1f} TF ({tf/2500*100:4.1f}%)'
+        hip.lib().so.varhip_conv16_force_tile(0)
+        print(line, flush=True)
+        del x, w, out, r, part
+
+
 def run_attn16(iters):
     dev = 'cuda'
     B2, H, Lmax = 128, 16, 680
@@ -158,5 +185,6 @@ if __name__ == '__main__':
     if a.what in ('qkv', 'all'): run_qkv(a.iters)
     if a.what in ('conv', 'all'): run_conv(a.iters)
     if a.what in ('attn', 'all'): run_attn(a.iters)
+    if a.what == 'conv16': run_conv16(a.iters)
     if a.what in ('gemm16', 'all16'): run_gemm16(a.iters)
     if a.what in ('attn16', 'all16'): run_attn16(a.iters)

@@ -2,7 +2,7 @@
 // accumulation on v_mfma_f32_16x16x32_f16, implicit GEMM (reference basic_vae.py:22-28,40-60,163-226 under the harness' fp16 autocast).
 // Not part of the fp32 parity contract (see gemm16.hip); the decoder is off the token path in either mode.
 //
-// Same scheme as the CONV instantiations of k_dma_gemm (gemm.hip): 128 output pixels x (32*TNW) output channels per workgroup, the
+// Same scheme as the CONV instantiations of k_dma_gemm (gemm.hip): 128 or 256 output pixels x (32*TNW) output channels per workgroup, the
 // input tile read through a buffer descriptor whose window starts one row + one pixel before the first sample the tile touches (a padded
 // tap ORs bit 31 into the lane offset: the hardware bounds check writes zeros), weights [Cout][tap][Cin], K order = 32-channel chunk
 // outermost, then tap (the taps of a chunk re-read the same cache lines), Upsample2x as four 2x2 phase convolutions.
@@ -35,15 +35,21 @@ template <int MAXA, int PER> __device__ __forceinline__ void vh16c_wait_dma_and_
     else { if (ahead >= MAXA) vh16c_waitcnt_barrier<MAXA * PER>(); else vh16c_wait_dma_and_barrier<MAXA - 1, PER>(ahead); }
 }
 
-template <int TNW, int NST>
-__global__ void __launch_bounds__(256, 2) k_conv16(Conv16P p) {
-    constexpr int TMW = 4, BM = 128, BN = TNW * 32, ROWB = 64;
-    constexpr int NIA = 2, NIB = (BN + 63) / 64;                  // DMA instructions (16 rows x 64 B) per wave and K tile
-    constexpr int BROWS = NIB * 64, STAGE = (BM + BROWS) * ROWB, PER = NIA + NIB;
-    static_assert((NST - 2) * PER <= 63, "vmcnt is a 6-bit counter");
+template <int TNW, int NST, int WM, int OCC = 2>
+__global__ void __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(WM * OCC / 2, WM * OCC / 2))) k_conv16(Conv16P p) {
+    // WM x 2 waves, each 64 pixels x (16*TNW) channels, OCC workgroups per CU: WM = 2 -> 128-pixel tiles; WM = 4 -> 256-pixel tiles (the weight
+    // tile is fetched from L2 once per 256 pixels: 98 instead of 71 FLOP per byte moved into LDS — that traffic, not the matrix pipe or the
+    // LDS reads, bounds the loop: with the loads taken out it runs no faster).  Two workgroups per CU either way: one's epilogue and pipeline
+    // fill hide behind the other's loop (one 8-wave workgroup per CU with 5 stages measured 15 % slower than two with 3).
+    constexpr int TMW = 4, NWAVE = WM * 2, BM = WM * 64, BN = TNW * 32, ROWB = 64;
+    constexpr int NIA = BM / 16 / NWAVE, NBT = BN / 16;           // DMA instructions (16 rows x 64 B) per K tile: NIA per wave for the pixels, NBT per workgroup for the weights
+    constexpr int NIB_HI = (NBT + NWAVE - 1) / NWAVE, NIB_LO = NBT / NWAVE, N_HI = NBT - NIB_LO * NWAVE;   // waves < N_HI issue NIB_HI weight loads, the rest NIB_LO
+    constexpr int STAGE = (BM + BN) * ROWB, PER_HI = NIA + NIB_HI, PER_LO = NIA + NIB_LO;
+    static_assert((NST - 2) * PER_HI <= 63, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) char smc[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
+    const bool hi_wave = wave < N_HI;
     int tm_, tn_;
     {
         const int nwg = p.tilesM * p.tilesN, bid = blockIdx.x;
@@ -65,7 +71,7 @@ __global__ void __launch_bounds__(256, 2) k_conv16(Conv16P p) {
     const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + (int64_t)cv_b0 * sample - shift), 0,
                                                                             (int)((((int64_t)(mlast / hw - cv_b0 + 1)) * sample + shift) * 2), 0x00020000);
     const int drow = lane >> 2, dslot = lane & 3, dchunk = dslot ^ ((-(drow >> 2)) & 3);
-    uint32_t aoff[NIA], abad[NIA], boff[NIB];
+    uint32_t aoff[NIA], abad[NIA], boff[NIB_HI];
     const int dy0 = p.phase ? (bz >> 1) - 1 : -1, dx0 = p.phase ? (bz & 1) - 1 : -1;
 #pragma unroll
     for (int i = 0; i < NIA; ++i) {
@@ -78,14 +84,14 @@ __global__ void __launch_bounds__(256, 2) k_conv16(Conv16P p) {
                           : ((r0 ? 0x007u : 0u) | (r1 ? 0x038u : 0u) | (r2 ? 0x1C0u : 0u) | (c0 ? 0x049u : 0u) | (c1 ? 0x092u : 0u) | (c2 ? 0x124u : 0u));
     }
 #pragma unroll
-    for (int i = 0; i < NIB; ++i) {
-        int n = n0 + (wave * NIB + i) * 16 + drow; n = n < p.N ? n : p.N - 1;
+    for (int i = 0; i < NIB_HI; ++i) {                            // weight load i of this wave covers rows 16*(wave + NWAVE*i) .. +15 of the tile
+        int n = n0 + (wave + NWAVE * i) * 16 + drow; n = n < p.N ? n : p.N - 1;
         boff[i] = (uint32_t)(((int64_t)n * p.K + dchunk * 8) * 2);
     }
     int cv_tap = 0, cv_cc = 0;                                    // tap / channel chunk of the next K tile to be requested (tiles are requested in order)
     auto dma_tile = [&](int st) {
         char* sA = smc + st * STAGE + wave * NIA * 16 * ROWB;
-        char* sB = smc + st * STAGE + BM * ROWB + wave * NIB * 16 * ROWB;
+        char* sB = smc + st * STAGE + BM * ROWB + wave * 16 * ROWB;
         const int tap = cv_tap, ci0 = cv_cc * 32;
         if (++cv_tap == ntap) { cv_tap = 0; ++cv_cc; }
         int dy, dx;
@@ -96,8 +102,13 @@ __global__ void __launch_bounds__(256, 2) k_conv16(Conv16P p) {
         for (int i = 0; i < NIA; ++i)
             vh16c_dma_buf(arsrc, ((abad[i] >> tap) << 31) | aoff[i], soff, (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(sA + i * 16 * ROWB));
 #pragma unroll
-        for (int i = 0; i < NIB; ++i)
-            vh16c_dma_glob((const char*)Wb + (size_t)(tap * p.Cin + ci0) * 2, boff[i], (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(sB + i * 16 * ROWB));
+        for (int i = 0; i < NIB_HI; ++i)
+            if (i < NIB_LO || hi_wave)
+                vh16c_dma_glob((const char*)Wb + (size_t)(tap * p.Cin + ci0) * 2, boff[i], (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(sB + i * NWAVE * 16 * ROWB));
+    };
+    auto wait_tile = [&](int ahead) {                             // this wave's requests for the tile about to be read have landed; then everyone's
+        if (PER_HI != PER_LO && hi_wave) vh16c_wait_dma_and_barrier<NST - 2, PER_HI>(ahead);
+        else vh16c_wait_dma_and_barrier<NST - 2, PER_LO>(ahead);
     };
 
     f32x4 acc[TMW][TNW];
@@ -114,13 +125,13 @@ __global__ void __launch_bounds__(256, 2) k_conv16(Conv16P p) {
     if (idle_wave) {                                              // same requests and barriers, no matrix work (kept out of the hot loop)
         for (int kt = 0; kt < nk; ++kt) {
             const int ahead = (nk - 1 - kt) < (NST - 2) ? (nk - 1 - kt) : (NST - 2);
-            vh16c_wait_dma_and_barrier<NST - 2, PER>(ahead);
+            wait_tile(ahead);
             if (kt + NST - 1 < nk) dma_tile((kt + NST - 1) % NST);
         }
     } else {
         for (int kt = 0; kt < nk; ++kt) {
             const int ahead = (nk - 1 - kt) < (NST - 2) ? (nk - 1 - kt) : (NST - 2);
-            vh16c_wait_dma_and_barrier<NST - 2, PER>(ahead);
+            wait_tile(ahead);
             const int cur = kt % NST;
             const char* sA = smc + cur * STAGE + (wm * TMW * 16 + r16) * ROWB + rsl;
             const char* sB = smc + cur * STAGE + BM * ROWB + (wn * TNW * 16 + r16) * ROWB + rsl;
@@ -141,7 +152,71 @@ __global__ void __launch_bounds__(256, 2) k_conv16(Conv16P p) {
     // ---- epilogue: acc[i][j][e] = C[pixel m = tile_m(i) + r16][channel n = tile_n(j) + 4*kq + e]
     const int nw0 = n0 + wn * TNW * 16;
     const bool vec = !(p.N & 3);
-    if (nw0 < p.N) {
+    constexpr int SROW = TNW * 64 + 16, STG = 16 * SROW;          // fp32 staging: 16 pixels x (16*TNW) channels per wave, rows padded by 16 B (conflict-free b128 writes)
+    double* const red = reinterpret_cast<double*>(smc + NWAVE * STG);
+    static_assert((size_t)NWAVE * STG + (size_t)WM * BN * 2 * sizeof(double) <= (size_t)NST * STAGE, "epilogue staging must fit in the stages");
+    if (vec && p.out_mode == 0) {
+        // Through LDS, 16 pixels at a time and private to the wave (no workgroup barrier): the accumulator layout gives a lane 4 channels of
+        // one pixel, so direct stores are 32-byte pieces of 16 different rows per instruction — measured at a third of the kernel's time on
+        // the 160-channel maps.  Read back, NC = 4*TNW consecutive lanes cover one pixel's 32*TNW bytes: the residual read and the store are
+        // contiguous runs, and each lane keeps ONE 4-channel column over all its pixels, which is what the GroupNorm partial needs.
+        constexpr int NC = TNW * 4, PXI = 64 / NC, NIT = (16 + PXI - 1) / PXI;
+        char* const stg = smc + wave * STG;
+        const int col = lane % NC, pl = lane / NC;
+        const int n = nw0 + col * 4;
+        const bool lane_on = pl < PXI && n < p.N;
+        float b4[TNW][4];
+#pragma unroll
+        for (int j = 0; j < TNW; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const int nn = nw0 + j * 16 + kq * 4 + e; b4[j][e] = nn < p.N ? p.bias[nn] : 0.f; }
+        float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};      // fp32 over this lane's <= 64 / PXI pixels (values are fp16: 11 bits), fp64 from there on
+#pragma unroll
+        for (int i = 0; i < TMW; ++i) {
+            const int mrow = m0 + (wm * TMW + i) * 16;
+            if (mrow >= p.M) break;                                           // wave-uniform
+#pragma unroll
+            for (int j = 0; j < TNW; ++j) {
+                f32x4 v = acc[i][j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] + b4[j][e];
+                *(f32x4*)(stg + r16 * SROW + (j * 16 + kq * 4) * 4) = v;
+            }
+            int mo16 = 0;                                                     // phase mode: output row of pixel (lane & 15) of this pass, handed to its reader below
+            if (p.phase) {
+                int m = mrow + r16; m = m < p.M ? m : p.M - 1;
+                const int b = m / hw, rem2 = m - b * hw, y = rem2 / p.Wd, x = rem2 - y * p.Wd;
+                mo16 = (b * (2 * p.H) + 2 * y + (bz >> 1)) * (2 * p.Wd) + 2 * x + (bz & 1);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // the wave's own LDS traffic is in order; this keeps the compiler from moving the reads up
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+                const int px = pl + PXI * k, m = mrow + px;
+                const int mo_ph = __shfl(mo16, px & 15, 64);
+                if (!lane_on || px >= 16 || m >= p.M) continue;
+                f32x4 v = *(const f32x4*)(stg + px * SROW + col * 16);
+                if (p.resid) { const h4 r4 = *(const h4*)(p.resid + (int64_t)m * p.N + n);
+#pragma unroll
+                               for (int e = 0; e < 4; ++e) v[e] = (float)r4[e] + v[e]; }
+                h4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
+                *(h4*)((_Float16*)p.out + (int64_t)(p.phase ? mo_ph : m) * p.N + n) = o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = (float)o[e]; gs[e] += d; gq[e] += d * d; }     // statistics of what the next GroupNorm will read: the rounded values
+            }
+            asm volatile("" ::: "memory");
+        }
+        if (p.gn_part) {                                                      // host guarantees full tiles; lanes pl = 0..PXI-1 hold the same column
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float s = gs[e], q = gq[e];
+#pragma unroll
+                for (int t = 1; t < PXI; ++t) { s += __shfl(gs[e], lane + NC * t, 64); q += __shfl(gq[e], lane + NC * t, 64); }
+                if (pl == 0 && n < p.N) { const int nl = wn * TNW * 16 + col * 4 + e; red[(wm * BN + nl) * 2] = (double)s; red[(wm * BN + nl) * 2 + 1] = (double)q; }
+            }
+        }
+    } else if (nw0 < p.N) {                                                   // the decoder's last conv (fp32 NCHW, <= 3 channels) and channel counts that are not multiples of 4
 #pragma unroll
         for (int j = 0; j < TNW; ++j) {
             const int n = nw0 + j * 16 + kq * 4;
@@ -149,7 +224,6 @@ __global__ void __launch_bounds__(256, 2) k_conv16(Conv16P p) {
             float b4[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) b4[e] = (n + e < p.N) ? p.bias[n + e] : 0.f;
-            double gs[4] = {0.0, 0.0, 0.0, 0.0}, gq[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int i = 0; i < TMW; ++i) {
                 const int m = m0 + (wm * TMW + i) * 16 + r16;
@@ -158,7 +232,7 @@ __global__ void __launch_bounds__(256, 2) k_conv16(Conv16P p) {
                 f32x4 v = acc[i][j];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = v[e] + b4[e];
-                if (p.out_mode != 0) {                                      // last conv: fp32 NCHW store of <= 3 channels, clamp (+ de-normalise)
+                if (p.out_mode != 0) {                                      // fp32 NCHW store, clamp (+ de-normalise)
                     for (int e = 0; e < 4; ++e) {
                         if (n + e >= p.N) break;
                         const float x = vm_min(vm_max(v[e], -1.0f), 1.0f);
@@ -168,72 +242,54 @@ __global__ void __launch_bounds__(256, 2) k_conv16(Conv16P p) {
                 }
                 int64_t mo = m;                                             // output row; the phase mode scatters to the 2x grid
                 if (p.phase) { const int y = rem2 / p.Wd, x = rem2 - y * p.Wd; mo = ((int64_t)b * (2 * p.H) + 2 * y + (bz >> 1)) * (2 * p.Wd) + 2 * x + (bz & 1); }
-                if (vec) {
-                    if (p.resid) { const h4 r4 = *(const h4*)(p.resid + (int64_t)m * p.N + n);
-#pragma unroll
-                                   for (int e = 0; e < 4; ++e) v[e] = (float)r4[e] + v[e]; }
-                    h4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
-                    *(h4*)((_Float16*)p.out + mo * p.N + n) = o;
-                    if (p.gn_part) {                                        // statistics of what the next GroupNorm will read: the rounded values
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { const double d = (double)(float)o[e]; gs[e] += d; gq[e] += d * d; }
-                    }
-                } else {
-                    for (int e = 0; e < 4; ++e) {
-                        if (n + e >= p.N) break;
-                        float x = v[e];
-                        if (p.resid) x = (float)p.resid[(int64_t)m * p.N + n + e] + x;
-                        ((_Float16*)p.out)[mo * p.N + n + e] = (_Float16)x;
-                    }
-                }
-            }
-            if (p.gn_part) {                                                // host guarantees full tiles and N % 4 == 0
-#pragma unroll
-                for (int off = 8; off >= 1; off >>= 1)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { gs[e] += __shfl_xor(gs[e], off, 64); gq[e] += __shfl_xor(gq[e], off, 64); }
-                if (r16 == 0) {
-                    double* red = reinterpret_cast<double*>(smc);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int nl = (wn * TNW + j) * 16 + kq * 4 + e;
-                        red[(wm * BN + nl) * 2] = gs[e]; red[(wm * BN + nl) * 2 + 1] = gq[e];
-                    }
+                for (int e = 0; e < 4; ++e) {
+                    if (n + e >= p.N) break;
+                    float x = v[e];
+                    if (p.resid) x = (float)p.resid[(int64_t)m * p.N + n + e] + x;
+                    ((_Float16*)p.out)[mo * p.N + n + e] = (_Float16)x;
                 }
             }
         }
     }
     if (p.gn_part) {
         __syncthreads();
-        if (tid < BN) {
-            const double* red = reinterpret_cast<const double*>(smc);
-            const double s = red[tid * 2] + red[(BN + tid) * 2], q = red[tid * 2 + 1] + red[(BN + tid) * 2 + 1];
-            const int b = m0 / hw, per = hw / BM, blk = bz * per + (m0 - b * hw) / BM, nblk = (int)gridDim.z * per;
-            double* o = p.gn_part + (((int64_t)b * nblk + blk) * p.N + n0 + tid) * 2;
-            o[0] = s; o[1] = q;
+        if (tid < BN) {                                             // one partial per 128-pixel block (varhip_conv_gn_blocks), WM / 2 of them per tile
+#pragma unroll
+            for (int hb = 0; hb < WM / 2; ++hb) {
+                const int mh = m0 + hb * 128;
+                if (mh >= p.M) break;
+                const double s = red[(2 * hb * BN + tid) * 2] + red[((2 * hb + 1) * BN + tid) * 2];
+                const double q = red[(2 * hb * BN + tid) * 2 + 1] + red[((2 * hb + 1) * BN + tid) * 2 + 1];
+                const int b = mh / hw, per = hw / 128, blk = bz * per + (mh - b * hw) / 128, nblk = (int)gridDim.z * per;
+                double* o = p.gn_part + (((int64_t)b * nblk + blk) * p.N + n0 + tid) * 2;
+                o[0] = s; o[1] = q;
+            }
         }
     }
 }
 
-template <int TNW, int NST>
+template <int TNW, int NST, int WM, int OCC = 2>
 static int launch_conv16(Conv16P& p, int nz, hipStream_t s) {
-    constexpr int BN = TNW * 32, NIB = (BN + 63) / 64;
-    constexpr size_t lds = (size_t)NST * (128 + NIB * 64) * 64;
-    static_assert(lds >= (size_t)2 * BN * 2 * sizeof(double), "GroupNorm partials must fit in the stages");
-    p.tilesM = (p.M + 127) / 128; p.tilesN = (p.N + BN - 1) / BN;
-    auto kfn = k_conv16<TNW, NST>;
+    constexpr int BN = TNW * 32, BM = WM * 64;
+    constexpr size_t lds = (size_t)NST * (BM + BN) * 64;
+    static_assert(lds <= 160 * 1024 / OCC, "LDS budget of the intended occupancy");
+    p.tilesM = (p.M + BM - 1) / BM; p.tilesN = (p.N + BN - 1) / BN;
+    auto kfn = k_conv16<TNW, NST, WM, OCC>;
     static bool attr_done = false;
     if (!attr_done) { if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
-    hipLaunchKernelGGL(kfn, dim3(p.tilesM * p.tilesN, 1, nz), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(kfn, dim3(p.tilesM * p.tilesN, 1, nz), dim3(WM * 128), lds, s, p);
     return vh_launch_status();
 }
+static int g_conv16_force_wm = 0;                                 // 0: by size; 2 / 4: experiments (tools/bench_kernels.py, tests)
+extern "C" int varhip_conv16_force_tile(int wm) { g_conv16_force_wm = (wm == 2 || wm == 4) ? wm : 0; return 0; }
 static int dispatch_conv16(Conv16P& p, int nz, hipStream_t s) {
-    if (p.N % 160 == 0) return launch_conv16<5, 4>(p, nz, s);
-    if (p.N % 128 == 0) return launch_conv16<4, 4>(p, nz, s);
-    if (p.N % 64 == 0) return launch_conv16<2, 4>(p, nz, s);
-    return launch_conv16<1, 4>(p, nz, s);
+    // 256-pixel tiles (8 waves, two workgroups per CU) once they give every CU a workgroup
+    const int64_t big_wgs = (int64_t)((p.M + 255) / 256) * ((p.N + 159) / 160) * nz;
+    const bool big = g_conv16_force_wm ? g_conv16_force_wm == 4 : big_wgs >= 256;
+    if (p.N % 160 == 0) return big ? launch_conv16<5, 3, 4, 2>(p, nz, s) : launch_conv16<5, 4, 2>(p, nz, s);
+    if (p.N % 128 == 0) return big ? launch_conv16<4, 3, 4, 2>(p, nz, s) : launch_conv16<4, 4, 2>(p, nz, s);
+    if (p.N % 64 == 0) return launch_conv16<2, 4, 2>(p, nz, s);
+    return launch_conv16<1, 4, 2>(p, nz, s);
 }
 
 static int conv16_checks(const void* in, const void* w, const float* bias, const void* out, int B, int H, int W, int Cin, int Cout) {
@@ -253,7 +309,7 @@ extern "C" int varhip_conv3x3_nhwc_f16(const void* in, const void* w, const floa
     if (gn_part && (!varhip_conv_gn_blocks(H, W, Cout, 0) || (Cout & 3))) return VARHIP_EINVAL;
     if ((int64_t)Cout * 9 * Cin * 2 >= (1ll << 32)) return VARHIP_EINVAL;
     {   const int64_t hw = (int64_t)H * W, sample = hw * Cin;
-        if (((127 / hw + 2) * sample + (int64_t)(W + 1) * Cin) * 2 >= (1ll << 31)) return VARHIP_EINVAL; }
+        if (((255 / hw + 2) * sample + (int64_t)(W + 1) * Cin) * 2 >= (1ll << 31)) return VARHIP_EINVAL; }
     Conv16P p{};
     p.in = (const _Float16*)in; p.w = (const _Float16*)w; p.bias = bias; p.out = out; p.resid = (const _Float16*)resid; p.gn_part = gn_part;
     p.M = B * H * W; p.N = Cout; p.K = 9 * Cin; p.H = H; p.Wd = W; p.Cin = Cin; p.phase = 0; p.out_mode = out_mode; p.sW = 0;
@@ -272,7 +328,7 @@ extern "C" int varhip_upconv_phase_f16(const void* in, const void* w_phase, cons
     if ((H & 1) || (W & 1) || (Cout & 3)) return VARHIP_EINVAL;
     if (gn_part && !varhip_conv_gn_blocks(H, W, Cout, 1)) return VARHIP_EINVAL;
     {   const int64_t hw = (int64_t)(H / 2) * (W / 2), sample = hw * Cin;
-        if (((127 / hw + 2) * sample + (int64_t)(W / 2 + 1) * Cin) * 2 >= (1ll << 31)) return VARHIP_EINVAL; }
+        if (((255 / hw + 2) * sample + (int64_t)(W / 2 + 1) * Cin) * 2 >= (1ll << 31)) return VARHIP_EINVAL; }
     Conv16P p{};
     p.in = (const _Float16*)in; p.w = (const _Float16*)w_phase; p.bias = bias; p.out = out; p.resid = nullptr; p.gn_part = gn_part;
     p.M = B * (H / 2) * (W / 2); p.N = Cout; p.K = 4 * Cin; p.H = H / 2; p.Wd = W / 2; p.Cin = Cin; p.phase = 1; p.out_mode = 0;
