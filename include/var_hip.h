@@ -300,7 +300,7 @@ int varhip_conv3x3_nhwc_f16(const void* in, const void* w, const float* bias, co
 int varhip_upconv_phase_f16(const void* in, const void* w_phase, const float* bias, void* out, double* gn_part,
                             int B, int H, int W, int Cin, int Cout, varhip_stream_t stream);
 /* testing / experiments: force the pixel tile of the following f16 convolutions (2: 128 pixels, 4 waves, two workgroups per CU;
- * 4: 256 pixels, 8 waves, two workgroups per CU; anything else: by size) */
+ * 4: 256 pixels, 8 waves, two workgroups per CU; 8: the halo-patch kernel where the shape allows it; anything else: by size) */
 int varhip_conv16_force_tile(int wm);
 /* GroupNorm on fp16 [B][HW][C] (basic_vae.py:18-19): statistics in fp64, affine + optional SiLU in fp32, fp16 result */
 int varhip_gn_stats_f16(const void* x, float* stats, double* scratch, int B, int HW, int C, int G, float eps, varhip_stream_t stream);

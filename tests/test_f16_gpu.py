@@ -147,19 +147,21 @@ def test_attn16_against_twin(B2, l, H, curL):
 
 
 @pytest.mark.parametrize('B,H,W,Cin,Cout,res,omode', [(2, 16, 16, 32, 32, 0, 0), (2, 16, 16, 640, 640, 1, 0), (1, 32, 32, 320, 160, 0, 0), (3, 8, 8, 160, 160, 1, 0),
-                                                      (2, 32, 32, 160, 3, 0, 1), (1, 16, 16, 64, 3, 0, 2), (1, 24, 40, 96, 64, 1, 0), (1, 24, 16, 64, 128, 1, 0)])
-@pytest.mark.parametrize('wm', [2, 4])
+                                                      (2, 32, 32, 160, 3, 0, 1), (1, 16, 16, 64, 3, 0, 2), (1, 24, 40, 96, 64, 1, 0), (1, 24, 16, 64, 128, 1, 0),
+                                                      (2, 8, 64, 32, 128, 1, 0), (1, 32, 16, 64, 128, 0, 0), (2, 16, 32, 160, 320, 1, 0), (3, 16, 64, 96, 160, 0, 0)])
+@pytest.mark.parametrize('wm', [2, 4, 8])
 def test_conv16_against_float64(B, H, W, Cin, Cout, res, omode, wm):
-    """both pixel tiles (128 pixels x 4 waves, 256 pixels x 8 waves), forced: the automatic choice takes the large one only once it fills the chip"""
+    """the three kernels, forced (the automatic choice takes the large ones only once they fill the chip): 128 pixels x 4 waves, 256 pixels x 8
+    waves, and (8) the halo-patch kernel on the shapes it takes — 8x32 or 16x16 patches, 128 | Cout or 160 | Cout — falling back to the first otherwise"""
     hip = _hip()
     hip.lib().so.varhip_conv16_force_tile(wm)
     try:
-        _conv16_case(hip, B, H, W, Cin, Cout, res, omode)
+        _conv16_case(hip, B, H, W, Cin, Cout, res, omode, blocks_2d=(wm == 8))
     finally:
         hip.lib().so.varhip_conv16_force_tile(0)
 
 
-def _conv16_case(hip, B, H, W, Cin, Cout, res, omode):
+def _conv16_case(hip, B, H, W, Cin, Cout, res, omode, blocks_2d=False):
     g = torch.Generator().manual_seed(H * 31 + Cin + Cout)
     x = torch.randn(B, H, W, Cin, generator=g).half()
     w = (torch.randn(Cout, 3, 3, Cin, generator=g) * (1.0 / (9 * Cin) ** 0.5)).half()
@@ -179,7 +181,10 @@ def _conv16_case(hip, B, H, W, Cin, Cout, res, omode):
     tol = 1e-5 + (0 if omode else ref.abs() * 2.0 ** -10) + 2e-6 * (9 * Cin) ** 0.5
     err = (got - ref).abs()
     assert bool((err <= tol).all()), f'max err {float(err.max()):.3e}'
-    if nblk:                                                     # GroupNorm partials: sums of the ROUNDED outputs, per block of 128 pixels
+    if nblk and blocks_2d:                                       # the halo-patch kernel's blocks are halves of its 2-D patches: any partition of a sample serves the statistics
+        o = out.double().cpu().view(B, H * W, Cout)
+        assert torch.allclose(part[..., 0].sum(1).cpu(), o.sum(1), rtol=1e-5, atol=1e-3) and torch.allclose(part[..., 1].sum(1).cpu(), (o * o).sum(1), rtol=1e-5, atol=1e-3)
+    elif nblk:                                                   # GroupNorm partials: sums of the ROUNDED outputs, per block of 128 pixels
         o = out.double().cpu().view(B, nblk, 128, Cout)
         # fp32 inside a wave (<= 16 of the fp16 values per lane, then 64 / PXI lanes), fp64 across waves, blocks and in the statistics kernel
         assert torch.allclose(part[..., 0].cpu(), o.sum(2), rtol=1e-5, atol=1e-4) and torch.allclose(part[..., 1].cpu(), (o * o).sum(2), rtol=1e-5, atol=1e-4)
@@ -378,8 +383,10 @@ def test_f16_mode_properties_d16_full():
         assert torch.equal(a, b) and torch.equal(ia, torch.cat(eng.last_trace['idx'], dim=1))
         sub = eng.sample(2, labels[1:3], None, 1.5, 900, 0.96, noises=[n.view(B, -1, V)[1:3].reshape(-1, V) for n in noise], trace=True)
         assert torch.equal(torch.cat(eng.last_trace['idx'], dim=1), ia[1:3]), 'tokens must not depend on the batch neighbours'
-        # (pixels: the decoder's GroupNorm statistics pass splits its fp64 partial sums by the batch size at 256x256: last-bit differences)
-        assert float((sub - a[1:3]).abs().max()) <= 1e-5
+        # pixels: which conv16 kernel runs depends on the number of tiles, i.e. on the batch, and the kernels sum their GroupNorm partials in
+        # different orders (fp32 inside a wave): a statistic moves in its 7th digit, an activation on a rounding boundary moves by one fp16 ulp
+        # (5e-4 at magnitude 1) and the layers above carry that on: a few fp16 ulps at the output, far inside the mode's 2e-2 pixel budget
+        assert float((sub - a[1:3]).abs().max()) <= 5e-3
         assert torch.isfinite(a).all() and float(a.min()) >= 0 and float(a.max()) <= 1
     finally:
         var.set_hip_precision('f32')

@@ -137,7 +137,7 @@ def run_gemm16(iters, rounds=3):
 def run_conv16(iters):
     """the 16-bit mode's decoder convolutions at the d16 / B=64 shapes, both pixel tiles (CONV16_TILES=2,4; 0 = automatic)"""
     dev = 'cuda'
-    tiles = [int(t) for t in os.environ.get('CONV16_TILES', '2,4').split(',')]
+    tiles = [int(t) for t in os.environ.get('CONV16_TILES', '2,4,8').split(',')]
     for (B, H, W, Cin, Cout, up2, res) in [(64, 256, 256, 160, 160, 0, 1), (64, 256, 256, 160, 160, 1, 0), (64, 128, 128, 320, 160, 0, 0), (64, 128, 128, 160, 160, 0, 1),
                                            (64, 128, 128, 320, 320, 1, 0), (64, 64, 64, 320, 320, 0, 1), (64, 32, 32, 640, 320, 0, 0), (64, 32, 32, 640, 640, 1, 0), (64, 16, 16, 640, 640, 0, 1)]:
         Hi, Wi = (H // 2, W // 2) if up2 else (H, W)

@@ -268,6 +268,191 @@ __global__ void __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(W
     }
 }
 
+// ---- k_conv16h: the same convolution with the INPUT tile fetched once per 32-channel chunk instead of once per tap.
+// k_conv16's loop is bound by the bytes it moves from L2 into LDS (98 FLOP per byte at best; with the loads taken out it runs no
+// faster), and 62 % of those bytes are the nine shifted copies of the same input pixels.  Here a workgroup owns a PH x PW patch of one
+// image (256 pixels); per chunk, the (PH+2) x (PW+2) halo patch goes to LDS once (out-of-image pixels arrive as zeros through the
+// descriptor's bounds check) and the nine taps read it at nine row offsets: 112 instead of 234 KiB-pieces per chunk for 160 output channels.
+// Roles: waves 0..NBW-1 stream the weights (a [BN][32] tile per tap, three stages, two pieces per wave and step, s_waitcnt vmcnt(2)),
+// the other waves fetch the next chunk's patch during taps 0..ASTEPS-1 of the current one (two pieces per step, double-buffered) —
+// every wave's wait count is then a constant.  LDS rows of 64 bytes: slot c of row r holds chunk c ^ (((r >> 2) & 1) << 1), the one
+// family of swizzles under which ds_read_b128 of 16 CONSECUTIVE rows is conflict-free at ANY starting row (the taps shift it).
+template <int TNW, int PW>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) k_conv16h(Conv16P p) {
+    constexpr int TMW = 4, BN = TNW * 32, ROWB = 64;
+    constexpr int PH = 256 / PW, P = PW + 2, PROWS = (PH + 2) * P, NPIECE = (PROWS + 15) / 16, PATCH = NPIECE * 1024;
+    constexpr int NBT = BN / 16, NBW = NBT / 2, NAW = 8 - NBW, KP = (NPIECE + NAW - 1) / NAW, ASTEPS = (KP + 1) / 2;
+    constexpr int BST = BN * ROWB;
+    static_assert(NBT % 2 == 0 && NAW >= 1 && ASTEPS <= 6, "roles");
+    extern __shared__ __attribute__((aligned(16))) char smc[];
+    char* const sB = smc + 2 * PATCH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const bool b_wave = wave < NBW;
+    int tm_, tn_;
+    {
+        const int nwg = p.tilesM * p.tilesN, bid = blockIdx.x;
+        const int q = nwg >> 3, rem = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        const int lin = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + loc;      // an XCD works on consecutive tiles: neighbours share halo rows, and one weight slice
+        tn_ = lin / p.tilesM; tm_ = lin - tn_ * p.tilesM;
+    }
+    const int tX = p.Wd / PW, tY = p.H / PH, tps = tX * tY;
+    const int b = tm_ / tps, trem = tm_ - b * tps, tyi = trem / tX, ty0 = tyi * PH, tx0 = (trem - tyi * tX) * PW;
+    const int n0 = tn_ * BN, hw = p.H * p.Wd;
+    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + (int64_t)b * hw * p.Cin), 0, (int)((int64_t)hw * p.Cin * 2), 0x00020000);
+    const int drow = lane >> 2, dchunk = (lane & 3) ^ (((lane >> 4) & 1) << 1);
+
+    const uint32_t boff = (uint32_t)(((int64_t)(n0 + wave * 32 + drow) * p.K + dchunk * 8) * 2);
+    auto dma_b = [&](int c, int tap, int st) {                    // weight tile of (chunk c, tap) -> stage st
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            vh16c_dma_glob((const char*)p.w + (size_t)(tap * p.Cin + c * 32) * 2 + (size_t)i * 16 * p.K * 2, boff,
+                           (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(sB + st * BST + (wave * 2 + i) * 1024));
+    };
+    // source offsets of the patch pieces (piece j, lane) -> LDS table, once: the tile's geometry costs a dozen VALU and a 64-bit temporary
+    // per piece, and the loop below has no register to spare (a spill there would also put scratch traffic on the vmcnt the pipeline counts)
+    uint32_t* const atab = reinterpret_cast<uint32_t*>(smc + 2 * PATCH + 3 * BST);
+    for (int e = tid; e < NPIECE * 64; e += 512) {
+        const int l = e & 63, pr = (e >> 6) * 16 + (l >> 2), py = pr / P, px = pr - py * P, y = ty0 - 1 + py, x = tx0 - 1 + px;
+        const bool bad = pr >= PROWS || (unsigned)y >= (unsigned)p.H || (unsigned)x >= (unsigned)p.Wd;
+        atab[e] = bad ? 0x80000000u : (uint32_t)(((y * p.Wd + x) * p.Cin + ((l & 3) ^ (((l >> 4) & 1) << 1)) * 8) * 2);
+    }
+    __syncthreads();
+    const uint32_t* const atab_l = atab + ((b_wave ? 0 : wave - NBW) * 64 + lane);      // one address register; the piece index is an immediate offset
+    auto dma_a = [&](int c, int k) {                              // piece k of this wave's share of chunk c's patch
+        const int j = (wave - NBW) + NAW * k;
+        if (k >= KP || j >= NPIECE) return;                       // wave-uniform
+        vh16c_dma_buf(arsrc, atab_l[NAW * 64 * k], (uint32_t)(c * 64), (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(smc + (c & 1) * PATCH + j * 1024));
+    };
+
+    f32x4 acc[TMW][TNW];
+#pragma unroll
+    for (int i = 0; i < TMW; ++i)
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int r16 = lane & 15, kq = lane >> 4;
+    int rb = (PW == 32 ? wm * 2 * P : wm * 4 * P) + r16;          // patch row of this lane's pixel of fragment 0 at tap (0, 0)
+    const int bsl = (wn * TNW * 16 + r16) * ROWB + ((kq << 4) ^ (((r16 >> 2) & 1) << 5));
+    const int nch = p.Cin / 32;
+
+    if (b_wave) { dma_b(0, 0, 0); dma_b(0, 1, 1); }
+    else {
+#pragma unroll
+        for (int k = 0; k < KP; ++k) dma_a(0, k);
+    }
+    for (int c = 0; c < nch; ++c) {
+        const char* const pa = smc + (c & 1) * PATCH;
+        asm volatile("" : "+v"(rb));                                          // keeps the 36 tap addresses from being hoisted out of the chunk loop (they would spill)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const bool last = (c == nch - 1) && t == 8;
+            if (b_wave) { if (last) vh16c_waitcnt_barrier<0>(); else vh16c_waitcnt_barrier<2>(); }        // this step's weight tile (and whatever is older) has landed
+            else if (t == 0) vh16c_waitcnt_barrier<0>();                                                  // this wave's share of the patch has landed
+            else asm volatile("s_barrier" ::: "memory");
+            if (b_wave) {                                                                               // two steps ahead; stage (t + 2) % 3 was read last in the previous step
+                if (t < 7) dma_b(c, t + 2, (t + 2) % 3);
+                else if (c + 1 < nch) dma_b(c + 1, t - 7, (t + 2) % 3);
+            } else if (t < ASTEPS && c + 1 < nch) { dma_a(c + 1, 2 * t); dma_a(c + 1, 2 * t + 1); }      // the other patch buffer was read last in the previous chunk
+            const int ky = t / 3, kx = t - ky * 3;
+            const char* const sb = sB + (t % 3) * BST + bsl;
+            // rolling fragments: all of the weight tile's, two of the pixels' at a time (28 instead of 36 registers: the budget is 128)
+            h8 bn[TNW], am[2];
+            auto lda = [&](int i) { const int R = rb + (PW == 32 ? (i >> 1) * P + (i & 1) * 16 : i * P) + ky * P + kx;
+                                    return *(const h8*)(pa + R * ROWB + ((kq << 4) ^ (((R >> 2) & 1) << 5))); };
+            am[0] = lda(0);
+#pragma unroll
+            for (int j = 0; j < TNW; ++j) bn[j] = *(const h8*)(sb + j * 16 * ROWB);
+            am[1] = lda(1);
+#pragma unroll
+            for (int i = 0; i < TMW; ++i) {
+#pragma unroll
+                for (int j = 0; j < TNW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bn[j], am[i & 1], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (i + 2 < TMW) am[i & 1] = lda(i + 2);
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);                            // nothing of the epilogue moves up into the last taps (it spilled accumulators there)
+    __syncthreads();                                              // patches and stages are free: the epilogue reuses them
+    asm volatile("" ::: "memory");
+
+    // ---- epilogue (as k_conv16's staged one; tiles are always full here)
+    constexpr int SROW = TNW * 64 + 16, STG = 16 * SROW, NC = TNW * 4, PXI = 64 / NC, NIT = (16 + PXI - 1) / PXI;
+    static_assert((size_t)8 * STG + (size_t)4 * BN * 2 * sizeof(double) <= (size_t)2 * PATCH + 3 * BST, "epilogue staging must fit");
+    double* const red = reinterpret_cast<double*>(smc + 8 * STG);
+    char* const stg = smc + wave * STG;
+    const int nw0 = n0 + wn * TNW * 16, col = lane % NC, pl = lane / NC, n = nw0 + col * 4;
+    const bool lane_on = pl < PXI;
+    float b4[TNW][4];
+#pragma unroll
+    for (int j = 0; j < TNW; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b4[j][e] = p.bias[nw0 + j * 16 + kq * 4 + e];
+    float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < TMW; ++i) {
+        const int trow = PW == 32 ? wm * 2 + (i >> 1) : wm * 4 + i, x0 = PW == 32 ? (i & 1) * 16 : 0;
+        const int64_t mrow = ((int64_t)b * p.H + ty0 + trow) * p.Wd + tx0 + x0;
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) {
+            f32x4 v = acc[i][j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] + b4[j][e];
+            *(f32x4*)(stg + r16 * SROW + (j * 16 + kq * 4) * 4) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int px = pl + PXI * k;
+            if (!lane_on || px >= 16) continue;
+            const int64_t m = mrow + px;
+            f32x4 v = *(const f32x4*)(stg + px * SROW + col * 16);
+            if (p.resid) { const h4 r4 = *(const h4*)(p.resid + m * p.N + n);
+#pragma unroll
+                           for (int e = 0; e < 4; ++e) v[e] = (float)r4[e] + v[e]; }
+            h4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
+            *(h4*)((_Float16*)p.out + m * p.N + n) = o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = (float)o[e]; gs[e] += d; gq[e] += d * d; }
+        }
+        asm volatile("" ::: "memory");
+    }
+    if (p.gn_part) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float sm = gs[e], q = gq[e];
+#pragma unroll
+            for (int t = 1; t < PXI; ++t) { sm += __shfl(gs[e], lane + NC * t, 64); q += __shfl(gq[e], lane + NC * t, 64); }
+            if (pl == 0) { const int nl = wn * TNW * 16 + col * 4 + e; red[(wm * BN + nl) * 2] = (double)sm; red[(wm * BN + nl) * 2 + 1] = (double)q; }
+        }
+        __syncthreads();
+        if (tid < BN) {                                             // two partials per tile (its upper and lower 128 pixels); any partition of a sample's pixels serves the statistics
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                const double sm = red[(2 * hb * BN + tid) * 2] + red[((2 * hb + 1) * BN + tid) * 2];
+                const double q = red[(2 * hb * BN + tid) * 2 + 1] + red[((2 * hb + 1) * BN + tid) * 2 + 1];
+                double* o = p.gn_part + (((int64_t)b * (2 * tps) + 2 * trem + hb) * p.N + n0 + tid) * 2;
+                o[0] = sm; o[1] = q;
+            }
+        }
+    }
+}
+
+template <int TNW, int PW>
+static int launch_conv16h(Conv16P& p, hipStream_t s) {
+    constexpr int BN = TNW * 32, PH = 256 / PW, NPIECE = ((PH + 2) * (PW + 2) + 15) / 16;
+    constexpr size_t lds = (size_t)2 * NPIECE * 1024 + (size_t)3 * BN * 64 + (size_t)NPIECE * 256;
+    static_assert(lds <= 80 * 1024, "two workgroups per CU");
+    p.tilesM = (p.M / (p.H * p.Wd)) * (p.H / PH) * (p.Wd / PW); p.tilesN = p.N / BN;
+    auto kfn = k_conv16h<TNW, PW>;
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+    hipLaunchKernelGGL(kfn, dim3(p.tilesM * p.tilesN), dim3(512), lds, s, p);
+    return vh_launch_status();
+}
+
 template <int TNW, int NST, int WM, int OCC = 2>
 static int launch_conv16(Conv16P& p, int nz, hipStream_t s) {
     constexpr int BN = TNW * 32, BM = WM * 64;
@@ -281,8 +466,17 @@ static int launch_conv16(Conv16P& p, int nz, hipStream_t s) {
     return vh_launch_status();
 }
 static int g_conv16_force_wm = 0;                                 // 0: by size; 2 / 4: experiments (tools/bench_kernels.py, tests)
-extern "C" int varhip_conv16_force_tile(int wm) { g_conv16_force_wm = (wm == 2 || wm == 4) ? wm : 0; return 0; }
+extern "C" int varhip_conv16_force_tile(int wm) { g_conv16_force_wm = (wm == 2 || wm == 4 || wm == 8) ? wm : 0; return 0; }
 static int dispatch_conv16(Conv16P& p, int nz, hipStream_t s) {
+    // the halo-patch kernel: plain 3x3 convs on maps that tile into 8x32 or 16x16 patches, once there is a workgroup for every CU
+    if (!p.phase && p.out_mode == 0 && g_conv16_force_wm != 2 && g_conv16_force_wm != 4 && (p.N % 160 == 0 || p.N % 128 == 0)
+        && (int64_t)p.H * p.Wd * p.Cin * 2 < (1ll << 31)
+        && (g_conv16_force_wm == 8 || (int64_t)(p.M / 256) * (p.N / (p.N % 160 == 0 ? 160 : 128)) >= 256)) {
+        const int64_t wgs = (int64_t)(p.M / 256) * (p.N / (p.N % 160 == 0 ? 160 : 128));
+        const bool w32 = (p.Wd % 32 == 0) && (p.H % 8 == 0), w16 = (p.Wd % 16 == 0) && (p.H % 16 == 0) && (g_conv16_force_wm == 8 || wgs >= 512);
+        if (w32) return p.N % 160 == 0 ? launch_conv16h<5, 32>(p, s) : launch_conv16h<4, 32>(p, s);
+        if (w16) return p.N % 160 == 0 ? launch_conv16h<5, 16>(p, s) : launch_conv16h<4, 16>(p, s);
+    }
     // 256-pixel tiles (8 waves, two workgroups per CU) once they give every CU a workgroup
     const int64_t big_wgs = (int64_t)((p.M + 255) / 256) * ((p.N + 159) / 160) * nz;
     const bool big = g_conv16_force_wm ? g_conv16_force_wm == 4 : big_wgs >= 256;
