@@ -110,7 +110,7 @@ def run_gemm16(iters, rounds=3):
     """the 16-bit mode's GEMM (varhip_gemm_nt_f16) at the d16 / B=64 shapes; TFLOP/s against the 2.5 PF dense fp16 peak"""
     dev = 'cuda'
     res, bufs = {}, {}
-    shapes = [s_ for s_ in gemm_shapes() if s_[1] >= 2048]
+    shapes = [s_ for s_ in gemm_shapes() if int(os.environ.get('GEMM16_MINM', 2048)) <= s_[1] <= int(os.environ.get('GEMM16_MAXM', 1 << 30))]
     for name, M, N, K, epi in shapes:
         A = torch.randn(M, K, device=dev).half(); W = (torch.randn(N, K, device=dev) * 0.03).half(); b = torch.randn(N, device=dev)
         out16 = torch.empty(M, N, device=dev, dtype=torch.float16); out32 = torch.empty(M, N, device=dev); resid = torch.randn(M, N, device=dev); gamma = torch.randn(128, N, device=dev)
