@@ -211,12 +211,22 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) k_gemm16(Gemm16P p) {
             return;
         }
     }
+    // Every other case (the 2x2-wave tiles, and partial 256x256 tiles): staged through LDS too, 16 rows at a time and private to the wave (no
+    // workgroup barrier; the K loop ended on one, so the stages are free).  The accumulator layout gives a lane 4 columns of one row: direct
+    // stores are 64-byte (fp32) or 32-byte (fp16) pieces of 16 rows per instruction.  Read back, NC = 4*TNW consecutive lanes cover one row's
+    // 16*TNW columns: residual reads and stores are contiguous runs of 64*TNW (fp32) / 32*TNW (fp16) bytes, 64 / NC rows per instruction.
     const int nw0 = n0 + wn * TNW * 16;
-    if (nw0 >= p.N) return;
-    if constexpr (TNW == 4) {
-        if (p.epi == 3) {
+    if (nw0 >= p.N || m0 + wm * TMW * 16 >= p.M) return;
+    constexpr int SROWW = TNW * 64 + 16, STGW = 16 * SROWW, NC = TNW * 4, RPI = 64 / NC, NIT = 16 / RPI;
+    static_assert((size_t)NWAVE * STGW <= (size_t)2 * STAGE, "epilogue staging must fit in the stages");
+    char* const stg = smem16 + wave * STGW;
+    const int col = lane % NC, rl = lane / NC, n = nw0 + col * 4;
+    const bool n_ok = n < p.N;                                      // (N % 4 == 0: host-checked)
+    char* Ob = (char*)p.out + (int64_t)bz * p.sO * (p.out_f16 ? 2 : 4);
+    if (p.epi == 3) {
+        if constexpr (TNW == 4) {
             // fused q/k/v post-processing (basic_var.py:98-109): the wave's 64 columns are one head of q, k or v.  L2 norm, scale and the
-            // sum of squares in fp32 on the accumulators; q and the cache rows leave as fp16.
+            // sum of squares in fp32 on the accumulators; q and the cache rows leave as fp16, one 128-byte head row per 16 lanes.
             const int C = p.N / 3, sect = nw0 / C, head = (nw0 - sect * C) >> 6, Hh = C >> 6;
             f32x4 b4[4];
 #pragma unroll
@@ -224,18 +234,19 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) k_gemm16(Gemm16P p) {
             const float sm = (p.q_l2 && sect == 0) ? vm_exp(vm_min(p.q_smul[head], 4.605170249938965f)) : 1.0f;
 #pragma unroll
             for (int i = 0; i < TMW; ++i) {
-                const int m = m0 + (wm * TMW + i) * 16 + r16;
+                const int mrow = m0 + (wm * TMW + i) * 16;
+                if (mrow >= p.M) break;
                 f32x4 v[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = acc[i][j] + b4[j];
                 if (p.q_l2 && sect < 2) {
                     const f32x4 a0 = v[0] * v[0] + v[2] * v[2], a1 = v[1] * v[1] + v[3] * v[3];
-                    f32x4 b = a0 + a1;
+                    f32x4 bsum = a0 + a1;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) b[e] = b[e] + __shfl_xor(b[e], 32, 64);
+                    for (int e = 0; e < 4; ++e) bsum[e] = bsum[e] + __shfl_xor(bsum[e], 32, 64);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) b[e] = b[e] + __shfl_xor(b[e], 16, 64);
-                    const float t0 = b[0] + b[2], t1 = b[1] + b[3];
+                    for (int e = 0; e < 4; ++e) bsum[e] = bsum[e] + __shfl_xor(bsum[e], 16, 64);
+                    const float t0 = bsum[0] + bsum[2], t1 = bsum[1] + bsum[3];
                     const float rn = (sect == 0 ? sm : 1.0f) / vm_max(vm_sqrt(t0 + t1), 1e-12f);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = v[j] * rn;
@@ -243,35 +254,45 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) k_gemm16(Gemm16P p) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = v[j] * p.q_plain;
                 }
-                if (m >= p.M) continue;
-                _Float16* dst;
-                if (sect == 0) dst = p.q_out + (int64_t)m * C + head * 64;
-                else {
-                    const int bb = m / p.q_l, t = m - bb * p.q_l;
-                    dst = (sect == 1 ? p.q_kc : p.q_vc) + (((int64_t)bb * Hh + head) * p.q_Lmax + p.q_pos0 + t) * 64;
-                }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    h4 o; o[0] = (_Float16)v[j][0]; o[1] = (_Float16)v[j][1]; o[2] = (_Float16)v[j][2]; o[3] = (_Float16)v[j][3];
-                    *(h4*)(dst + j * 16 + kq * 4) = o;
+                for (int j = 0; j < 4; ++j) *(f32x4*)(stg + r16 * SROWW + (j * 16 + kq * 4) * 4) = v[j];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int k = 0; k < NIT; ++k) {
+                    const int rr = rl + RPI * k, m = mrow + rr;
+                    if (m >= p.M) continue;
+                    const f32x4 w = *(const f32x4*)(stg + rr * SROWW + col * 16);
+                    _Float16* dst;
+                    if (sect == 0) dst = p.q_out + (int64_t)m * C + head * 64;
+                    else { const int bb = m / p.q_l, t = m - bb * p.q_l; dst = (sect == 1 ? p.q_kc : p.q_vc) + (((int64_t)bb * Hh + head) * p.q_Lmax + p.q_pos0 + t) * 64; }
+                    h4 o; o[0] = (_Float16)w[0]; o[1] = (_Float16)w[1]; o[2] = (_Float16)w[2]; o[3] = (_Float16)w[3];
+                    *(h4*)(dst + col * 4) = o;
                 }
+                asm volatile("" ::: "memory");
             }
-            return;
         }
+        return;
     }
-    char* Ob = (char*)p.out + (int64_t)bz * p.sO * (p.out_f16 ? 2 : 4);
+    f32x4 b4[TNW];
 #pragma unroll
-    for (int j = 0; j < TNW; ++j) {
-        const int n = nw0 + j * 16 + kq * 4;
-        if (n >= p.N) continue;                                     // (N % 4 == 0: host-checked)
-        const f32x4 b4 = p.bias ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TNW; ++j) { const int nn = nw0 + j * 16 + kq * 4; b4[j] = (p.bias && nn < p.N) ? *(const f32x4*)(p.bias + nn) : f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-        for (int i = 0; i < TMW; ++i) {
-            const int m = m0 + (wm * TMW + i) * 16 + r16;
-            if (m >= p.M) continue;
-            f32x4 v = acc[i][j] + b4;
+    for (int i = 0; i < TMW; ++i) {
+        const int mrow = m0 + (wm * TMW + i) * 16;
+        if (mrow >= p.M) break;                                     // wave-uniform
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) {
+            f32x4 v = acc[i][j] + b4[j];
             if (p.epi == VARHIP_EPI_GELU) { v[0] = vh16_gelu(v[0]); v[1] = vh16_gelu(v[1]); v[2] = vh16_gelu(v[2]); v[3] = vh16_gelu(v[3]); }
-            else if (p.epi == VARHIP_EPI_RESID) {
+            *(f32x4*)(stg + r16 * SROWW + (j * 16 + kq * 4) * 4) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the wave's own LDS traffic is in order; this keeps the compiler from moving the reads up
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int rr = rl + RPI * k, m = mrow + rr;
+            if (m >= p.M || !n_ok) continue;
+            f32x4 v = *(const f32x4*)(stg + rr * SROWW + col * 16);
+            if (p.epi == VARHIP_EPI_RESID) {
                 if (p.gamma) v = v * *(const f32x4*)(p.gamma + (int64_t)(m / p.rows_per_group) * p.ldg + n);
                 if (p.resid_f16) { const h4 r4 = *(const h4*)((const _Float16*)p.resid + (int64_t)m * p.ldr + n);
                                    v[0] = (float)r4[0] + v[0]; v[1] = (float)r4[1] + v[1]; v[2] = (float)r4[2] + v[2]; v[3] = (float)r4[3] + v[3]; }
@@ -281,6 +302,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) k_gemm16(Gemm16P p) {
                              *(h4*)(Ob + ((int64_t)m * p.ldo + n) * 2) = o; }
             else *(f32x4*)(Ob + ((int64_t)m * p.ldo + n) * 4) = v;
         }
+        asm volatile("" ::: "memory");
     }
 }
 
