@@ -171,11 +171,21 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) k_gemm16(Gemm16P p) {
             if (p.epi == 3) { Cq = p.N / 3; sect = n / Cq; head = (n - sect * Cq) >> 6; Hh = Cq >> 6;
                               sm = (p.q_l2 && sect == 0) ? vm_exp(vm_min(p.q_smul[head], 4.605170249938965f)) : 1.0f; }
             char* Ob = (char*)p.out + (int64_t)bz * p.sO * (p.out_f16 ? 2 : 4);
+            // fp32 residual rows: requested one pass ahead (fetched inside the pass, each of the 8 passes waited out a memory latency)
+            const bool res32 = p.epi == VARHIP_EPI_RESID && !p.resid_f16;
+            f32x4 rcur[4], rnxt[4];
+            auto res_rows = [&](int i, f32x4* r) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) { const int sr = 4 * wave + rr, m = m0 + (sr >> 4) * (TMW * 16) + i * 16 + (sr & 15);
+                                                 r[rr] = *(const f32x4*)((const float*)p.resid + (int64_t)m * p.ldr + n); }
+            };
+            if (res32) res_rows(0, rcur);
 #pragma unroll
             for (int i = 0; i < TMW; ++i) {
                 char* wr = smem16 + (wm * 16 + r16) * SROW + (wn * 64 + kq * 4) * 4;
 #pragma unroll
                 for (int j = 0; j < TNW; ++j) *(f32x4*)(wr + j * 64) = acc[i][j];
+                if (res32 && i + 1 < TMW) res_rows(i + 1, rnxt);
                 __syncthreads();
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
@@ -200,12 +210,14 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) k_gemm16(Gemm16P p) {
                         if (p.gamma) v = v * *(const f32x4*)(p.gamma + (int64_t)(m / p.rows_per_group) * p.ldg + n);
                         if (p.resid_f16) { const h4 r4 = *(const h4*)((const _Float16*)p.resid + (int64_t)m * p.ldr + n);
                                            v[0] = (float)r4[0] + v[0]; v[1] = (float)r4[1] + v[1]; v[2] = (float)r4[2] + v[2]; v[3] = (float)r4[3] + v[3]; }
-                        else v = *(const f32x4*)((const float*)p.resid + (int64_t)m * p.ldr + n) + v;
+                        else v = rcur[rr] + v;
                     }
                     if (p.out_f16) { h4 o; o[0] = (_Float16)v[0]; o[1] = (_Float16)v[1]; o[2] = (_Float16)v[2]; o[3] = (_Float16)v[3];
                                      *(h4*)(Ob + ((int64_t)m * p.ldo + n) * 2) = o; }
                     else *(f32x4*)(Ob + ((int64_t)m * p.ldo + n) * 4) = v;
                 }
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) rcur[rr] = rnxt[rr];
                 __syncthreads();
             }
             return;
@@ -276,6 +288,22 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) k_gemm16(Gemm16P p) {
     f32x4 b4[TNW];
 #pragma unroll
     for (int j = 0; j < TNW; ++j) { const int nn = nw0 + j * 16 + kq * 4; b4[j] = (p.bias && nn < p.N) ? *(const f32x4*)(p.bias + nn) : f32x4{0.f, 0.f, 0.f, 0.f}; }
+    // the fp32 residual rows of the whole wave tile are requested before the first pass (4 registers per row piece: 64 at 4x4, the 2x2-wave
+    // kernels have them): fetched pass by pass, each pass waited out a full memory latency with four loads in flight
+    constexpr bool PRE = (TMW * NIT <= 16);
+    f32x4 rpre[PRE ? TMW * NIT : 1];
+    const bool res32 = p.epi == VARHIP_EPI_RESID && !p.resid_f16;
+    if constexpr (PRE) {
+        if (res32) {
+#pragma unroll
+            for (int i = 0; i < TMW; ++i)
+#pragma unroll
+                for (int k = 0; k < NIT; ++k) {
+                    const int m = m0 + (wm * TMW + i) * 16 + rl + RPI * k;
+                    rpre[i * NIT + k] = (m < p.M && n_ok) ? *(const f32x4*)((const float*)p.resid + (int64_t)m * p.ldr + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TMW; ++i) {
         const int mrow = m0 + (wm * TMW + i) * 16;
@@ -296,6 +324,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) k_gemm16(Gemm16P p) {
                 if (p.gamma) v = v * *(const f32x4*)(p.gamma + (int64_t)(m / p.rows_per_group) * p.ldg + n);
                 if (p.resid_f16) { const h4 r4 = *(const h4*)((const _Float16*)p.resid + (int64_t)m * p.ldr + n);
                                    v[0] = (float)r4[0] + v[0]; v[1] = (float)r4[1] + v[1]; v[2] = (float)r4[2] + v[2]; v[3] = (float)r4[3] + v[3]; }
+                else if constexpr (PRE) v = rpre[i * NIT + k] + v;
                 else v = *(const f32x4*)((const float*)p.resid + (int64_t)m * p.ldr + n) + v;
             }
             if (p.out_f16) { h4 o; o[0] = (_Float16)v[0]; o[1] = (_Float16)v[1]; o[2] = (_Float16)v[2]; o[3] = (_Float16)v[3];
@@ -322,13 +351,14 @@ static int g_force_tile16 = -1;
 // testing / experiments: force the tile of the next varhip_gemm_nt_f16 / varhip_gemm_qkv_f16 calls (0: 128x128, 1: 64x64 (64x128 for q/k/v), 2: 256x256, -1: automatic)
 extern "C" int varhip_gemm16_force_tile(int tile) { g_force_tile16 = (tile >= 0 && tile <= 2) ? tile : -1; return 0; }
 
-static int pick_tile16(int M, int N, int batch) {
+static int pick_tile16(int M, int N, int batch, bool resid32 = false) {
     // 256x256 (8 waves, one workgroup per CU) when it gives every CU at least one tile and rounds of 256 lose little; 128x128 when that fills
     // the chip at least twice over; else 64x64 (K cannot be split without a reduction pass; the small scales are launch-latency bound anyway)
     if (g_force_tile16 >= 0) return g_force_tile16;
     const int64_t nb256 = (int64_t)((M + 255) / 256) * ((N + 255) / 256) * batch;
     const int64_t nb128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128) * batch;
-    if (nb256 >= 256 && (double)nb256 / (double)(((nb256 + 255) / 256) * 256) >= 0.8) return 2;
+    // (with the fp32 residual epilogue — attn.proj, ffn.fc2 — the large tile wins earlier: measured at M = 12800, N = 1024, 200 tiles on 256 CUs)
+    if (nb256 >= (resid32 ? 192 : 256) && (double)nb256 / (double)(((nb256 + 255) / 256) * 256) >= (resid32 ? 0.75 : 0.8)) return 2;
     return nb128 >= 512 ? 0 : 1;
 }
 
@@ -347,7 +377,7 @@ extern "C" int varhip_gemm_nt_f16(const void* A, int64_t lda, const void* W, int
     p.A = (const _Float16*)A; p.W = (const _Float16*)W; p.bias = bias; p.out = out; p.resid = resid; p.gamma = gamma;
     p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.ldr = ldr; p.ldg = ldg; p.sA = sA; p.sW = sW; p.sO = sO;
     p.M = M; p.N = N; p.K = K; p.epi = epi; p.rows_per_group = rows_per_group > 0 ? rows_per_group : 1; p.out_f16 = out_f16; p.resid_f16 = resid_f16;
-    const int pick = pick_tile16(M, N, batch);
+    const int pick = pick_tile16(M, N, batch, epi == VARHIP_EPI_RESID && !resid_f16);
     VhScope scope(pick == 2 ? VH_FAM_GEMM : VH_FAM_GEMM_SMALL, (hipStream_t)stream, 2.0 * M * N * (double)K * batch,
                   batch * (2.0 * ((double)M * K + (double)N * K) + (out_f16 ? 2.0 : 4.0) * (double)M * N));
     if (pick == 2) return launch16<8, 4, 2, 4>(p, batch, (hipStream_t)stream);
