@@ -127,7 +127,7 @@ def main():
         f = tt[dominant]
         achieved = f['flops'] / (f['ms'] * 1e-3) / 1e12 if f['ms'] > 0 else 0.0
         kname = {('gemm', False): 'k_dma_gemm<4,4,false,2,false>', ('conv3x3', False): 'k_dma_gemm<4,5,true,2,false>', ('attn', False): 'k_attn_cached<4>',
-                 ('gemm', True): 'k_gemm16<8,4,2,4>', ('conv3x3', True): 'k_conv16<5,4>', ('attn', True): 'k_attn16<4>'}[(dominant, f16)]
+                 ('gemm', True): 'k_gemm16<8,4,2,4>', ('conv3x3', True): 'k_conv16h<5,32>', ('attn', True): 'k_attn16<4>'}[(dominant, f16)]
         peak = fam_peak[dominant]
         traffic, tsrc = None, None                                   # HBM-side bytes per launch from a separate rocprofv3 --pmc pass of the same config
         for prof, pdt in ((f'r02_{args.dtype}_pmc_traffic.json', args.dtype), ('r01_pmc_traffic.json', 'f32')):
