@@ -147,14 +147,25 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) k_gemm16(Gemm16P p) {
     if (idle_wave) {
         for (int kt = 0; kt < nk; ++kt) { if (kt + 1 < nk) dma_tile(kt + 1, (kt & 1) ^ 1); vh16_waitcnt_barrier<0>(); }
     } else {
-        int kt = 0;
-        for (; kt + 1 < nk; kt += 2) {
-            compute(0, [&] { dma_tile(kt + 1, 1); });
-            vh16_waitcnt_barrier<0>();
-            compute(1, [&] { if (kt + 2 < nk) dma_tile(kt + 2, 0); });
-            vh16_waitcnt_barrier<0>();
+        if constexpr (TMW * TNW > 16) {
+            // one loop body, the stage a run-time offset: inlined once per stage, the accumulators get renamed between the two copies (232
+            // registers; 198 this way, same speed) and any further change to the schedule ends at the 256-register ceiling with a spill
+#pragma unroll 1
+            for (int kt = 0; kt < nk; ++kt) {
+                const int cur = kt & 1;
+                compute(cur, [&] { if (kt + 1 < nk) dma_tile(kt + 1, cur ^ 1); });
+                vh16_waitcnt_barrier<0>();
+            }
+        } else {
+            int kt = 0;
+            for (; kt + 1 < nk; kt += 2) {
+                compute(0, [&] { dma_tile(kt + 1, 1); });
+                vh16_waitcnt_barrier<0>();
+                compute(1, [&] { if (kt + 2 < nk) dma_tile(kt + 2, 0); });
+                vh16_waitcnt_barrier<0>();
+            }
+            if (kt < nk) { compute(0, [] {}); vh16_waitcnt_barrier<0>(); }
         }
-        if (kt < nk) { compute(0, [] {}); vh16_waitcnt_barrier<0>(); }
     }
 
     // ---- epilogue: acc[i][j][e] = C[m = tile_m(i) + r16][n = tile_n(j) + 4*kq + e]
