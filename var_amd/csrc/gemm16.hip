@@ -191,9 +191,13 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) k_gemm16(Gemm16P p) {
                                                  r[rr] = *(const f32x4*)((const float*)p.resid + (int64_t)m * p.ldr + n); }
             };
             if (res32) res_rows(0, rcur);
+            static_assert(2 * 32 * SROW <= 2 * STAGE, "two parking areas");
 #pragma unroll
             for (int i = 0; i < TMW; ++i) {
-                char* wr = smem16 + (wm * 16 + r16) * SROW + (wn * 64 + kq * 4) * 4;
+                // two parking areas in turn: pass i + 1 parks into the one pass i - 1 was read from, which every wave left before it arrived at
+                // the barrier of pass i — one barrier per pass instead of two
+                char* const park = smem16 + (i & 1) * 32 * SROW;
+                char* wr = park + (wm * 16 + r16) * SROW + (wn * 64 + kq * 4) * 4;
 #pragma unroll
                 for (int j = 0; j < TNW; ++j) *(f32x4*)(wr + j * 64) = acc[i][j];
                 if (res32 && i + 1 < TMW) res_rows(i + 1, rnxt);
@@ -201,7 +205,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) k_gemm16(Gemm16P p) {
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
                     const int sr = 4 * wave + rr, m = m0 + (sr >> 4) * (TMW * 16) + i * 16 + (sr & 15);
-                    f32x4 v = *(const f32x4*)(smem16 + sr * SROW + lane * 16) + b4;
+                    f32x4 v = *(const f32x4*)(park + sr * SROW + lane * 16) + b4;
                     if (p.epi == 3) {
                         if (p.q_l2 && sect < 2) {
                             float ss = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);      // a head = 16 lanes x 4 columns
@@ -229,7 +233,6 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) k_gemm16(Gemm16P p) {
                 }
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) rcur[rr] = rnxt[rr];
-                __syncthreads();
             }
             return;
         }
