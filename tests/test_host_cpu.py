@@ -299,6 +299,29 @@ def test_spawn_ranks_starts_n_ranks_and_relays_rank0_line(tmp_path):
     assert launch.under_launcher({'RANK': '0', 'WORLD_SIZE': '2'}) and not launch.under_launcher({})
 
 
+def test_launcher_counts_gpus_from_kfd_topology_without_loading_hip(tmp_path):
+    """launch._gpu_count reads /sys/class/kfd/kfd/topology/nodes/*/properties (GPU node: simd_count > 0 and an openable render node) and
+    the *_VISIBLE_DEVICES lists; the launcher parent never imports torch or loads libamdhip64 for it"""
+    from var_amd import launch
+    nodes, dri = tmp_path / 'nodes', tmp_path / 'dri'
+    dri.mkdir()
+    for i, (simd, minor) in enumerate([(0, None), (0, None), (1024, 128), (1024, 129), (1024, 130)]):      # 2 CPU agents, 3 GPUs
+        d = nodes / str(i); d.mkdir(parents=True)
+        (d / 'properties').write_text(f'cpu_cores_count {0 if simd else 64}\nsimd_count {simd}\n' + (f'drm_render_minor {minor}\n' if minor else ''))
+    for minor in (128, 129):                                       # the third GPU's render node is not handed to this container
+        (dri / f'renderD{minor}').write_text('')
+    assert launch._gpu_count(str(nodes), env={}, dri_dir=str(dri)) == 2
+    assert launch._gpu_count(str(nodes), env={'ROCR_VISIBLE_DEVICES': '1'}, dri_dir=str(dri)) == 1
+    assert launch._gpu_count(str(nodes), env={'HIP_VISIBLE_DEVICES': '0,1,2,3'}, dri_dir=str(dri)) == 2
+    assert launch._gpu_count(str(nodes), env={'CUDA_VISIBLE_DEVICES': ''}, dri_dir=str(dri)) == 0
+    assert launch._gpu_count(str(tmp_path / 'absent'), env={}) == 0
+    code = (f'import sys; sys.path.insert(0, {ROOT!r}); from var_amd import launch; n = launch._gpu_count(); '
+            'maps = open("/proc/self/maps").read(); '
+            'assert "torch" not in sys.modules and "libamdhip64" not in maps and "libhsa-runtime" not in maps, "the launcher parent loaded a GPU runtime"; print(n)')
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr[-1500:]
+
+
 def test_bench_self_launches_when_asked_for_more_gpus_than_ranks(monkeypatch):
     """bench.py --gpus 2 outside torchrun must go through the launcher (and therefore fail here: this container has no GPU), never run
     one rank and report n_gpus 1."""

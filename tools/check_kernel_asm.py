@@ -1,0 +1,148 @@
+#!/usr/bin/env python3
+"""Build-time checks on the gfx950 assembly hipcc emits for the hand-scheduled kernels (run by var_amd/csrc/Makefile, target `asmcheck`,
+on `hipcc -S --cuda-device-only` output; tests/test_build_cpu.py runs it too).
+
+  python tools/check_kernel_asm.py [--no-scratch] [--mfma-hazard] file.s ...
+
+--no-scratch   every kernel of the file must have .private_segment_fixed_size 0, .vgpr_spill_count 0 and .sgpr_spill_count 0.
+               Why: k_gemm16 / k_conv16 / k_conv16h / k_attn* keep LDS-DMA tiles in flight behind hand-counted `s_waitcnt vmcnt(N)`.
+               vmcnt counts every vector-memory operation of the wave in issue order, so a compiler-inserted scratch access can only make
+               such a wait cover MORE (never fewer) of the older requests — results stay right — but every scratch reload also brings the
+               compiler's own `s_waitcnt vmcnt(0)`, which drains the request pipeline the kernel was built around: a silent slowdown.
+               Several instantiations sit at their register cap, so a compiler update could start spilling without any source change.
+  --scratch-outside-loops-ok SUBSTR   kernels whose mangled name contains SUBSTR may spill OUTSIDE loops (prologue / epilogue code that runs
+               once per tile); scratch instructions inside a loop still fail.
+  --scratch-ok SUBSTR                 kernels that are known to spill inside their loop (listed with the reason in the Makefile).
+
+--mfma-hazard  no instruction of an inline-asm block may touch the destination registers of an MFMA whose result has not been
+               "settled".  hipcc pads the MFMA -> VALU read/write hazard (up to 18 wait states behind a 16-pass v_mfma) for ITS OWN
+               instructions only; an `asm("v_max3_f32 ...")` placed first behind the score MFMAs of the attention kernels read the
+               accumulators before the last MFMA had written them (round 2: run-to-run differences of the tile maximum that no
+               tolerance test caught).  An MFMA is settled once a compiler-generated (non-asm, non-MFMA) instruction has read or written
+               one of its destination registers (the compiler put the wait states in front of that instruction, and instructions issue
+               in order), or once 20 wait states' worth of instructions have issued behind it (`s_nop N` counts N + 1, anything else 1).
+"""
+import re
+import sys
+
+SETTLE_STATES = 20          # >= the largest MFMA -> VALU requirement on gfx950 (16-pass XDL op: 18) with margin
+
+_REG1 = re.compile(r'\b([va])(\d+)\b')
+_REGR = re.compile(r'\b([va])\[(\d+):(\d+)\]')
+_FUNC = re.compile(r'^([A-Za-z_][\w$]*):')          # a function label at column 0 (block labels start with .L)
+
+
+def regs_of(text):
+    out = set()
+    for m in _REGR.finditer(text):
+        out.update((m.group(1), i) for i in range(int(m.group(2)), int(m.group(3)) + 1))
+    for m in _REG1.finditer(text):
+        out.add((m.group(1), int(m.group(2))))
+    return out
+
+
+def check_hazards(lines, fname='<asm>'):
+    """-> list of violation strings"""
+    bad = []
+    pending = []            # [dest regs (set), wait states issued since, line number, text] of unsettled MFMAs, oldest first
+    in_asm = False
+    for ln, raw in enumerate(lines, 1):
+        s = raw.strip()
+        if s.startswith(';;#ASMSTART'):
+            in_asm = True; continue
+        if s.startswith(';;#ASMEND'):
+            in_asm = False; continue
+        if not s or s.startswith((';', '.', '//')) or s.endswith(':'):
+            if s.startswith('.amdhsa_kernel') or s.startswith('.end_amdhsa_kernel'):
+                pending = []
+            continue
+        code = s.split(';')[0].strip()
+        if not code:
+            continue
+        mnem = code.split()[0]
+        if mnem == 's_endpgm':
+            pending = []; continue
+        states = 1
+        if mnem == 's_nop':
+            try: states = int(code.split()[1], 0) + 1
+            except (IndexError, ValueError): states = 1
+        is_mfma = mnem.startswith(('v_mfma', 'v_smfmac'))
+        touched = regs_of(code[len(mnem):]) if mnem[0] in 'vdgbfs' else set()
+        if pending and touched:
+            hit = [i for i, p in enumerate(pending) if p[0] & touched]
+            if hit:
+                if in_asm:
+                    p = pending[hit[-1]]
+                    bad.append(f'{fname}:{ln}: inline-asm `{code}` touches the result of the MFMA at line {p[2]} (`{p[3]}`) only {p[1]} wait '
+                               f'state(s) behind it and before any compiler-generated reader')
+                elif not is_mfma:
+                    pending = pending[hit[-1] + 1:]          # the compiler padded this read: that MFMA and every older one have completed
+        for p in pending:
+            p[1] += states
+        pending = [p for p in pending if p[1] < SETTLE_STATES]
+        if is_mfma:
+            ops = code[len(mnem):].split(',')
+            dest = regs_of(ops[0]) if ops else set()
+            if dest:
+                pending.append([dest, 0, ln, code])
+    return bad
+
+
+def check_scratch(lines, fname='<asm>', outside_ok=(), ok=()):
+    """kernels with scratch / spills: refused, unless allowed outside loops (then every scratch instruction must sit in a block that is
+    not part of a loop) or allowed altogether"""
+    bad, name = [], '?'
+    spilling = {}
+    for raw in lines:
+        s = raw.strip()
+        if s.startswith('.name:'):
+            name = s.split(':', 1)[1].strip()
+        for key in ('.private_segment_fixed_size:', '.vgpr_spill_count:', '.sgpr_spill_count:'):
+            if s.startswith(key) and int(s.split(':', 1)[1]) != 0:
+                spilling.setdefault(name, []).append(s)
+    in_loop_scratch = {}
+    cur, in_loop = None, False
+    for ln, raw in enumerate(lines, 1):
+        s = raw.strip()
+        m = _FUNC.match(raw)
+        if m:
+            cur, in_loop = m.group(1), False
+        elif s.startswith('.LBB'):
+            in_loop = ('in Loop:' in s) or ('Loop Header' in s)
+        elif s.startswith('scratch_') and in_loop and cur is not None:
+            in_loop_scratch.setdefault(cur, []).append(ln)
+    for name, what in spilling.items():
+        if any(t in name for t in ok):
+            continue
+        if any(t in name for t in outside_ok):
+            if name in in_loop_scratch:
+                bad.append(f'{fname}: kernel {name}: scratch access inside a loop at line(s) {in_loop_scratch[name][:6]} (spills are tolerated outside loops only)')
+            continue
+        bad.append(f'{fname}: kernel {name}: ' + ', '.join(what) + '  (scratch reloads drain the LDS-DMA pipeline: vmcnt(0))')
+    return bad
+
+
+def main(argv):
+    want_scratch = '--no-scratch' in argv
+    want_hazard = '--mfma-hazard' in argv
+    outside_ok, ok, files, it = [], [], [], iter(argv)
+    for a in it:
+        if a == '--scratch-outside-loops-ok': outside_ok.append(next(it))
+        elif a == '--scratch-ok': ok.append(next(it))
+        elif not a.startswith('--'): files.append(a)
+    if not files or not (want_scratch or want_hazard):
+        print(__doc__); return 2
+    bad = []
+    for f in files:
+        lines = open(f).read().splitlines()
+        if want_scratch: bad += check_scratch(lines, f, outside_ok, ok)
+        if want_hazard: bad += check_hazards(lines, f)
+    for b in bad:
+        print('[asmcheck] ' + b, file=sys.stderr)
+    if not bad:
+        print(f'[asmcheck] ok: {len(files)} file(s)' + (' no scratch/spills' if want_scratch else '') + (' no asm reader of an unsettled MFMA result' if want_hazard else ''))
+    return 1 if bad else 0
+
+
+if __name__ == '__main__':
+    sys.exit(main(sys.argv[1:]))

@@ -114,14 +114,15 @@ class DecoderEngine(_VaeOps):
     """VQVAE.fhat_to_img on HIP kernels (reference vqvae.py:62-63, basic_vae.py:163-226)."""
 
     PREFIXES = ('decoder.', 'post_quant_conv.')
-    precision = 'f32'          # 'f16': fp16 activations / conv weights with fp32 accumulation (the 16-bit throughput mode); explicitly selected
+    # default precision of the VQVAE's own entry points (fhat_to_img, idxBl_to_img, ...): 'f32' unless the VQVAE's owner asks for 'f16'
+    # here.  The sampling loop does NOT change it: SamplingEngine passes its own precision with every decode_nhwc call, so two VARs
+    # sharing one VQVAE, or a VAR in the 16-bit mode next to direct VQVAE calls, never fight over a mode flag.
+    precision = 'f32'
 
     def set_precision(self, precision: str):
         if precision not in ('f32', 'f16'):
             raise ValueError("precision must be 'f32' or 'f16'")
-        if precision != self.precision:
-            self.precision = precision
-            self._sig = None
+        self.precision = precision
 
     def refresh(self):
         sig = self._signature()
@@ -134,12 +135,15 @@ class DecoderEngine(_VaeOps):
             hip.call('upconv_pack_f32', w[k], wp, cin, cout)
             w[k[:-len('weight')] + 'phase'] = wp
         self.w = w
-        self.w16 = {}
-        if self.precision == 'f16':          # fp16 copies of every conv kernel (3x3, phase, 1x1 shortcut); biases and GroupNorm affine stay fp32
-            self.w16 = {k: v.to(torch.float16).contiguous() for k, v in w.items()
-                        if (k.endswith('.weight') or k.endswith('.phase')) and v.dim() >= 2 and '.attn' not in k}
+        self.w16 = {}                        # fp16 copies: made by _ensure16() the first time a 16-bit decode runs on these weights
         self.nlev = 1 + max(int(k.split('.')[2]) for k in w if k.startswith('decoder.up.'))
         self._sig = sig
+
+    def _ensure16(self):
+        """fp16 copies of every conv kernel (3x3, phase, 1x1 shortcut) next to the fp32 ones; biases and GroupNorm affine stay fp32"""
+        if not self.w16:
+            self.w16 = {k: v.to(torch.float16).contiguous() for k, v in self.w.items()
+                        if (k.endswith('.weight') or k.endswith('.phase')) and v.dim() >= 2 and '.attn' not in k}
 
     # -- building blocks ---------------------------------------------------------------------------------------------
     def _part_buffer(self, B, nblk, Cout, dev):
@@ -315,11 +319,13 @@ class DecoderEngine(_VaeOps):
         h = self.gn16(h, 'decoder.norm_out', B, Hh * Ww, True)
         return self.conv3_16(h, 'decoder.conv_out', B, Hh, Ww, out_mode=1 if denorm else 2)
 
-    def decode_nhwc(self, f_hat: torch.Tensor, denorm: bool = True) -> torch.Tensor:
+    def decode_nhwc(self, f_hat: torch.Tensor, denorm: bool = True, precision: Optional[str] = None) -> torch.Tensor:
         """[B,P,P,Cvae] channels-last -> [B,3,16P,16P]; denorm=True: in [0,1] (clamp and (x+1)/2 fused into the last conv, what
-        autoregressive_infer_cfg returns); denorm=False: clamped to [-1,1] (VQVAE.fhat_to_img's contract)"""
+        autoregressive_infer_cfg returns); denorm=False: clamped to [-1,1] (VQVAE.fhat_to_img's contract).
+        precision: 'f32' / 'f16' for THIS call (None: the engine's default, `self.precision`)"""
         self.refresh()
-        if self.precision == 'f16':
+        if (precision or self.precision) == 'f16':
+            self._ensure16()
             return self._decode16(f_hat, denorm)
         B, P = f_hat.shape[0], f_hat.shape[1]
         Hh = Ww = P
@@ -566,10 +572,11 @@ class SamplingEngine:
     def set_precision(self, precision: str):
         """'f32' (default; the parity contract: token ids bit-identical to the CPU oracle) or 'f16': fp16 weights / GEMM operands / KV
         cache with fp32 accumulation on the f16 MFMAs — what the reference's harness asks for with torch.autocast(fp16)
-        (demo_sample.py:66-68).  LayerNorm statistics, AdaLN parameters, the residual stream, softmax, sampler, quantizer and decoder stay fp32."""
+        (demo_sample.py:66-68), and the decoder call that ends the loop runs on fp16 activations / conv weights too (conv16.hip).  LayerNorm /
+        GroupNorm statistics, AdaLN parameters, the residual stream, softmax, logits, sampler and quantizer stay fp32.  The VQVAE's own entry
+        points (fhat_to_img, idxBl_to_img, ...) are NOT switched: the shared DecoderEngine is told the precision per call."""
         if precision not in ('f32', 'f16'):
             raise ValueError("precision must be 'f32' or 'f16'")
-        self.dec.set_precision(precision)
         if precision != self.precision:
             self.precision = precision
             self._sig = None
@@ -803,7 +810,7 @@ class SamplingEngine:
         if not decode:
             return ws['f_hat'].permute(0, 3, 1, 2).contiguous()
         if ev: ev[S].record()
-        img = self.dec.decode_nhwc(ws['f_hat'])                           # var.py:190
+        img = self.dec.decode_nhwc(ws['f_hat'], precision=self.precision)     # var.py:190
         if ev:                                                            # tools/per_scale.py: ms per scale (blocks + head + sampler + quantizer step), then the decoder
             ev[S + 1].record(); torch.cuda.synchronize()
             self.last_scale_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(S + 1)]

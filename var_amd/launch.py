@@ -23,9 +23,39 @@ def free_port() -> int:
         return s.getsockname()[1]
 
 
-def _gpu_count() -> int:
-    import torch          # device_count() reads the driver's device list without creating a HIP context
-    return int(torch.cuda.device_count())
+KFD_NODES = '/sys/class/kfd/kfd/topology/nodes'
+
+
+def _visible_filter(n: int, env) -> int:
+    """apply ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES (comma lists; each narrows the previous one) to n GPUs"""
+    for k in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        v = env.get(k)
+        if v is not None:
+            n = min(n, len([t for t in v.split(',') if t.strip() != '']))
+    return n
+
+
+def _gpu_count(nodes_dir: str = KFD_NODES, env=None, dri_dir: str = '/dev/dri') -> int:
+    """GPUs of this node WITHOUT loading the HIP/HSA runtime into this process: the KFD topology lists one node per agent and a GPU
+    node is one with simd_count > 0 (CPU nodes have 0) whose render node (drm_render_minor) this process may open — a container that
+    was handed one GPU of eight still sees all eight in the topology.  torch.cuda.device_count() can fall through to
+    hipGetDeviceCount on ROCm, which would make the launcher a GPU-initialised parent of the ranks."""
+    env = os.environ if env is None else env
+    n = 0
+    try:
+        for node in sorted(os.listdir(nodes_dir)):
+            try:
+                with open(os.path.join(nodes_dir, node, 'properties')) as f:
+                    props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            except OSError:
+                continue
+            if int(props.get('simd_count', '0')) > 0:
+                minor = props.get('drm_render_minor')
+                if minor is None or os.access(os.path.join(dri_dir, f'renderD{minor}'), os.R_OK | os.W_OK):
+                    n += 1
+    except OSError:
+        return 0
+    return _visible_filter(n, env)
 
 
 def spawn_ranks(script: str, argv: List[str], nproc: int, device_count: Optional[Callable[[], int]] = None,
