@@ -12,6 +12,10 @@ fp32 MFMA peak.  --dtype f16: the 16-bit throughput mode of the transformer (fp1
 reference's harness requests with torch.autocast(fp16), demo_sample.py:66-68), priced against the 2.5 PF dense fp16 MFMA peak.
 
 Extra objects in the JSON line:
+  modes.f16    (default run, after the f32 timed region, same process / weights / workload) the 16-bit throughput mode: 2 warmup + >= 10 timed
+               steps between barriers, `value`, `ms_per_step`, its own measured dominant kernel with `roofline` and `whole_path`.  The
+               headline `value` / `dtype` stay f32.
+  ranks        (N > 1) each rank's own wall time per step, min and max over ranks, and the HIP-event time of the RCCL all-gather.
   roofline     the dominant kernel (largest device time among the single-symbol families, measured in the last warmup step with
                every family timed), re-timed alone with HIP events on the launch stream over the timed region: algorithmic FLOPs / time.
   whole_path   FLOPs per image as the reference computes them and as the kernels execute them (the decoder's Upsample2x convs run
@@ -35,7 +39,114 @@ if ROOT not in sys.path:
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4, 64 FLOP/clk/SIMD
 PEAK_F16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense BF16/FP16 MFMA
 PEAK_HBM_GBS = 8000.0
-MFMA_FAMILIES = ('gemm', 'gemm_small', 'conv3x3', 'conv_small', 'attn')
+# MFMA kernel families of the library's timing table (include/var_hip.h) and the peak each is priced against: a family holds kernels of
+# ONE arithmetic type.  In the 16-bit mode the fp32 families still run (AdaLN / head_nm projections, the decoder's four attention blocks).
+FAMILY_PEAK = {'gemm': PEAK_F32_MFMA_TFLOPS, 'gemm_small': PEAK_F32_MFMA_TFLOPS, 'conv3x3': PEAK_F32_MFMA_TFLOPS, 'conv_small': PEAK_F32_MFMA_TFLOPS,
+               'attn': PEAK_F32_MFMA_TFLOPS, 'gemm16': PEAK_F16_MFMA_TFLOPS, 'gemm16_small': PEAK_F16_MFMA_TFLOPS, 'conv16h': PEAK_F16_MFMA_TFLOPS,
+               'conv16_small': PEAK_F16_MFMA_TFLOPS, 'attn16': PEAK_F16_MFMA_TFLOPS}
+# families that can dominate a step -> the kernel symbol behind them (gemm / conv3x3 / gemm16 / conv16h: exactly one symbol; the attention
+# families: one template, 1-4 waves per workgroup by l)
+DOMINANT = {'f32': {'gemm': 'k_dma_gemm<4,4,false,2,false>', 'conv3x3': 'k_dma_gemm<4,5,true,2,false>', 'attn': 'k_attn_cached<NW>'},
+            'f16': {'gemm16': 'k_gemm16<8,4,2,4>', 'conv16h': 'k_conv16h<5,32>', 'attn16': 'k_attn16<NW>'}}
+
+
+def run_mode(var, dtype, steps, warmup, args, world, step_fn, dist, hip, torch):
+    """warm up and time `steps` calls in one precision mode; returns the raw measurements of this rank (dt already MAX-reduced over ranks)"""
+    var.set_hip_precision(dtype)
+    prepass = None
+    for i in range(warmup):
+        last = i == warmup - 1
+        if last: hip.timing_reset(); hip.timing_enable(True, None)
+        step_fn(i, None)
+        if last:
+            torch.cuda.synchronize(); hip.timing_enable(False); prepass = hip.timing_read()
+    fams = DOMINANT[dtype]
+    if prepass is not None:
+        dominant = max(fams, key=lambda k: prepass[k]['ms'])
+    else:
+        dominant = {'f32': 'conv3x3' if args.depth <= 16 else 'gemm', 'f16': 'gemm16'}[dtype]          # (--warmup 0)
+    hip.timing_reset(); hip.timing_enable(True, None if args.kernel_breakdown else [dominant])
+    gather_ev = []
+    dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        img = step_fn(1000 + i, gather_ev)
+    torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0                       # this rank's own time for the K steps (before waiting for the others)
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    hip.timing_enable(False)
+    tt = hip.timing_read()
+    B_total = args.batch * world
+    assert img.shape[0] == B_total and img.shape[1] == 3 and bool(torch.isfinite(img).all())
+    gather_ms = sum(a.elapsed_time(b) for a, b in gather_ev) / max(steps, 1)
+    ranks = None
+    if world > 1:
+        t = torch.tensor([dt, dt_own, gather_ms], device=img.device, dtype=torch.float64)
+        allt = [torch.empty_like(t) for _ in range(world)]
+        torch.distributed.all_gather(allt, t)
+        dt = max(float(x[0]) for x in allt)
+        ranks = {'rank_ms_min': round(min(float(x[1]) for x in allt) / steps * 1e3, 3), 'rank_ms_max': round(max(float(x[1]) for x in allt) / steps * 1e3, 3),
+                 'allgather_ms': round(max(float(x[2]) for x in allt), 3), 'allgather_ms_min': round(min(float(x[2]) for x in allt), 3),
+                 'allgather_mbytes': round(B_total * 3 * img.shape[2] * img.shape[3] * 4 / 1e6, 1),
+                 'note': 'rank_ms_*: each rank\'s own wall time per step for the timed region (sampling + decode + all-gather, before the closing barrier); '
+                         'allgather_ms: HIP-event time of the RCCL all-gather per step (max / min over ranks; a rank that arrives early waits inside it)'}
+    return dict(dt=dt, tt=tt, prepass=prepass, dominant=dominant, ranks=ranks, steps=steps, warmup=warmup, dtype=dtype)
+
+
+def describe_mode(m, args, world, var, pns):
+    """rank 0: the numbers of one precision mode as the JSON objects of the bench line"""
+    dtype, dt, tt, prepass, dominant, steps = m['dtype'], m['dt'], m['tt'], m['prepass'], m['dominant'], m['steps']
+    f16 = dtype == 'f16'
+    B_total = args.batch * world
+    ips = B_total * steps / dt
+    eng = var.engine()
+    flops_img = eng.flops_per_image()
+    dec_ref = eng.dec.flops_per_image_reference(pns[-1])        # as the reference computes the decoder (9-tap upsample convs)
+    dec_exec = eng.dec.flops_per_image_executed(pns[-1])        # as the kernels execute it (folded 4-tap upsample convs)
+    f = tt[dominant]
+    achieved = f['flops'] / (f['ms'] * 1e-3) / 1e12 if f['ms'] > 0 else 0.0
+    kname = DOMINANT[dtype][dominant]
+    peak = FAMILY_PEAK[dominant]
+    traffic, tsrc = None, None                                   # HBM-side bytes per launch from a separate rocprofv3 --pmc pass of the same config
+    for prof in (f'r03_{dtype}_pmc_traffic.json', f'r02_{dtype}_pmc_traffic.json'):
+        try:
+            pj = json.load(open(os.path.join(ROOT, 'profiles', prof)))
+            pm = pj['kernels'].get(kname)
+            if pm and args.batch == 64 and args.depth == 16:
+                traffic, tsrc = pm['traffic_bytes_per_launch'], f'profiles/{prof} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)'
+                break
+        except (OSError, KeyError, ValueError):
+            pass
+    whole_peak = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS
+    whole = {'gflop_per_image_reference': round((flops_img + dec_ref) / 1e9, 1), 'gflop_per_image_executed': round((flops_img + dec_exec) / 1e9, 1),
+             'tflops_reference': round(ips * (flops_img + dec_ref) / 1e12 / world, 2), 'tflops_executed': round(ips * (flops_img + dec_exec) / 1e12 / world, 2),
+             'frac_of_mfma_peak_reference_flops': round(ips * (flops_img + dec_ref) / 1e12 / world / whole_peak, 4),
+             'frac_of_mfma_peak_executed_flops': round(ips * (flops_img + dec_exec) / 1e12 / world / whole_peak, 4),
+             'peak_tflops': whole_peak,
+             'note': 'ada_lin counted once per call (hoisted; the reference recomputes it per scale)'}
+    table = tt if args.kernel_breakdown else prepass
+    if table is not None:
+        fams = [k for k in FAMILY_PEAK if table[k]['launches'] > 0]
+        ms = sum(table[k]['ms'] for k in fams); fl = sum(table[k]['flops'] for k in fams)
+        ideal_ms = sum(table[k]['flops'] / (FAMILY_PEAK[k] * 1e9) for k in fams)          # every family against the peak of ITS arithmetic type
+        whole['mfma_time_weighted'] = {'tflops': round(fl / (ms * 1e-3) / 1e12, 2) if ms > 0 else None,
+                                       'frac_of_peak': round(ideal_ms / ms, 4) if ms > 0 else None,
+                                       'device_ms_per_step': round(ms / (steps if args.kernel_breakdown else 1), 3),
+                                       'families': fams,
+                                       'source': 'timed region' if args.kernel_breakdown else 'last warmup step (every family timed)'}
+    roof = {'bound': 'mfma', 'kernel': kname, 'family': dominant, 'dominant_by': 'measured (last warmup step)' if prepass is not None else 'profile',
+            'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
+            'traffic': traffic, 'traffic_source': tsrc,
+            'launches': f['launches'], 'avg_launch_ms': round(f['ms'] / max(f['launches'], 1), 5),
+            'algorithmic_gflop_per_launch': round(f['flops'] / max(f['launches'], 1) / 1e9, 3),
+            'algorithmic_mbytes_per_launch': round(f['bytes'] / max(f['launches'], 1) / 1e6, 3)}
+    extra = {'kernel_time_ms_per_step': {k: round(v['ms'] / steps, 3) for k, v in tt.items() if v['launches'] > 0},
+             'kernel_tflops': {k: round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2) for k, v in tt.items() if v['ms'] > 0 and v['flops'] > 0},
+             'kernel_algorithmic_gbps': {k: round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1) for k, v in tt.items() if v['ms'] > 0 and v['bytes'] > 0}}
+    if prepass is not None:
+        extra['warmup_step_kernel_ms'] = {k: round(v['ms'], 3) for k, v in prepass.items() if v['launches'] > 0}
+    return ips, roof, whole, extra
 
 
 def main():
@@ -45,7 +156,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--batch', type=int, default=64, help='images per GPU (weak scaling)')
     ap.add_argument('--depth', type=int, default=16)
-    ap.add_argument('--dtype', default='f32', choices=['f32', 'f16'])
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'f16'], help='the mode of the headline value (default f32: the parity contract)')
+    ap.add_argument('--no-modes', action='store_true', help='skip the extra 16-bit-mode measurement that follows the f32 timed region (modes.f16)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--rng-mode', default='exact', choices=['exact', 'per_rank'])
     ap.add_argument('--host-init', action='store_true', help='generate the detinit weights with numpy on the host (same bits; keeps the ~8000 tiny init kernels out of a rocprofv3 counter pass)')
@@ -81,100 +193,47 @@ def main():
     fill_module_(var, args.depth, 0, 'var.'); fill_module_(vae, args.depth, 0, 'vae.')
     var.eval(); vae.eval()
     var.rng = torch.Generator(device=dev)
-    var.set_hip_precision(args.dtype)
 
     B_local, B_total = args.batch, args.batch * world
     labels = ((torch.arange(B_total) * 7) % 1000).to(dev)
 
-    def step(i):
-        return sample_sharded(var, B_total, labels, g_seed=i, cfg=1.5, top_k=900, top_p=0.96, rng_mode=args.rng_mode, gather=True)
+    def step(i, gather_ev):
+        return sample_sharded(var, B_total, labels, g_seed=i, cfg=1.5, top_k=900, top_p=0.96, rng_mode=args.rng_mode, gather=True, gather_events=gather_ev)
 
-    # warmup; the last warmup step runs with every family timed: it names the dominant kernel and gives the per-family table
-    prepass = None
-    for i in range(args.warmup):
-        last = i == args.warmup - 1
-        if last: hip.timing_reset(); hip.timing_enable(True, None)
-        step(i)
-        if last:
-            torch.cuda.synchronize(); hip.timing_enable(False); prepass = hip.timing_read()
-    if prepass is not None:
-        dominant = max(('gemm', 'conv3x3', 'attn'), key=lambda k: prepass[k]['ms'])       # the families that map to one kernel symbol each
-    else:
-        dominant = 'conv3x3' if (args.depth <= 16 and args.dtype == 'f32') else 'gemm'    # (--warmup 0: r01/r02 profiles)
-    hip.timing_reset(); hip.timing_enable(True, None if args.kernel_breakdown else [dominant])
-    dist.barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        img = step(1000 + i)
-    torch.cuda.synchronize(); dist.barrier()
-    dt = time.perf_counter() - t0
-    hip.timing_enable(False)
-    tt = hip.timing_read()
-    assert img.shape == (B_total, 3, 256, 256) and bool(torch.isfinite(img).all())
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    # the headline mode: W warmup steps (the last one with every family timed: it names the dominant kernel), then exactly K timed steps
+    head = run_mode(var, args.dtype, args.steps, args.warmup, args, world, step, dist, hip, torch)
+    # then, in the same process, the 16-bit throughput mode (what the reference's harness runs under torch.autocast(fp16)): its own warmup,
+    # >= 10 timed steps, its own dominant kernel and roofline.  The headline value / dtype stay those of the parity mode.
+    other = None
+    if args.dtype == 'f32' and not args.no_modes:
+        other = run_mode(var, 'f16', max(10, args.steps), 2, args, world, step, dist, hip, torch)
 
     if rank == 0:
-        f16 = args.dtype == 'f16'
-        ips = B_total * args.steps / dt
-        eng = var.engine()
-        flops_img = eng.flops_per_image()
-        dec_ref = eng.dec.flops_per_image_reference(pns[-1])        # as the reference computes the decoder (9-tap upsample convs)
-        dec_exec = eng.dec.flops_per_image_executed(pns[-1])        # as the kernels execute it (folded 4-tap upsample convs)
-        fam_peak = {k: (PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS) for k in MFMA_FAMILIES}
-        f = tt[dominant]
-        achieved = f['flops'] / (f['ms'] * 1e-3) / 1e12 if f['ms'] > 0 else 0.0
-        kname = {('gemm', False): 'k_dma_gemm<4,4,false,2,false>', ('conv3x3', False): 'k_dma_gemm<4,5,true,2,false>', ('attn', False): 'k_attn_cached<4>',
-                 ('gemm', True): 'k_gemm16<8,4,2,4>', ('conv3x3', True): 'k_conv16h<5,32>', ('attn', True): 'k_attn16<4>'}[(dominant, f16)]
-        peak = fam_peak[dominant]
-        traffic, tsrc = None, None                                   # HBM-side bytes per launch from a separate rocprofv3 --pmc pass of the same config
-        for prof, pdt in ((f'r02_{args.dtype}_pmc_traffic.json', args.dtype), ('r01_pmc_traffic.json', 'f32')):
-            try:
-                pj = json.load(open(os.path.join(ROOT, 'profiles', prof)))
-                pm = pj['kernels'].get(kname)
-                if pm and args.batch == 64 and args.depth == 16 and pdt == args.dtype:
-                    traffic, tsrc = pm['traffic_bytes_per_launch'], f'profiles/{prof} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)'
-                    break
-            except (OSError, KeyError, ValueError):
-                pass
-        whole_peak = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS
-        whole = {'gflop_per_image_reference': round((flops_img + dec_ref) / 1e9, 1), 'gflop_per_image_executed': round((flops_img + dec_exec) / 1e9, 1),
-                 'tflops_reference': round(ips * (flops_img + dec_ref) / 1e12 / world, 2), 'tflops_executed': round(ips * (flops_img + dec_exec) / 1e12 / world, 2),
-                 'frac_of_mfma_peak_reference_flops': round(ips * (flops_img + dec_ref) / 1e12 / world / whole_peak, 4),
-                 'frac_of_mfma_peak_executed_flops': round(ips * (flops_img + dec_exec) / 1e12 / world / whole_peak, 4),
-                 'peak_tflops': whole_peak,
-                 'note': 'ada_lin counted once per call (hoisted; the reference recomputes it per scale)'}
-        table = tt if args.kernel_breakdown else prepass
-        if table is not None:
-            ms = sum(table[k]['ms'] for k in MFMA_FAMILIES); fl = sum(table[k]['flops'] for k in MFMA_FAMILIES)
-            ideal_ms = sum(table[k]['flops'] / (fam_peak[k] * 1e9) for k in MFMA_FAMILIES)
-            whole['mfma_time_weighted'] = {'tflops': round(fl / (ms * 1e-3) / 1e12, 2) if ms > 0 else None,
-                                           'frac_of_peak': round(ideal_ms / ms, 4) if ms > 0 else None,
-                                           'device_ms_per_step': round(ms / (args.steps if args.kernel_breakdown else 1), 3),
-                                           'source': 'timed region' if args.kernel_breakdown else 'last warmup step (every family timed)'}
+        precision = {'f32': 'fp32 parity mode', 'f16': 'fp16 GEMM / conv operands, activations and KV cache, fp32 accumulate and statistics'}
+        var.set_hip_precision(args.dtype)
+        ips, roof, whole, extra = describe_mode(head, args, world, var, pns)
         out = {
             'metric': '256x256 images/sec (CFG=1.5) VAR-d%d' % args.depth, 'value': round(ips, 3), 'unit': 'images/sec', 'n_gpus': world,
-            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(head['dt'] / args.steps * 1e3, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'VAR-d{args.depth} 256x256 full 10-scale pyramid, CFG=1.5, top_k=900, top_p=0.96, batch={B_local}/GPU, random-init (detinit seed 0)',
                        'global_batch': B_total, 'parallelism': f'dp{world} (batch shard, RCCL all-gather of decoded images)', 'rng_mode': args.rng_mode,
-                       'precision': 'fp32 parity mode' if not f16 else 'fp16 GEMM / conv operands, activations and KV cache, fp32 accumulate and statistics'},
-            'roofline': {'bound': 'mfma', 'kernel': kname, 'dominant_by': 'measured (last warmup step)' if prepass is not None else 'profile',
-                         'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
-                         'traffic': traffic, 'traffic_source': tsrc,
-                         'launches': f['launches'], 'avg_launch_ms': round(f['ms'] / max(f['launches'], 1), 5),
-                         'algorithmic_gflop_per_launch': round(f['flops'] / max(f['launches'], 1) / 1e9, 3),
-                         'algorithmic_mbytes_per_launch': round(f['bytes'] / max(f['launches'], 1) / 1e6, 3)},
-            'kernel_time_ms_per_step': {k: round(v['ms'] / args.steps, 3) for k, v in tt.items() if v['launches'] > 0},
-            'kernel_tflops': {k: round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2) for k, v in tt.items() if v['ms'] > 0 and v['flops'] > 0},
-            'kernel_algorithmic_gbps': {k: round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1) for k, v in tt.items() if v['ms'] > 0 and v['bytes'] > 0},
+                       'precision': precision[args.dtype]},
+            'roofline': roof, **extra,
             'peak_hbm_allocated_gib': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
             'whole_path': whole,
         }
-        if prepass is not None:
-            out['warmup_step_kernel_ms'] = {k: round(v['ms'], 3) for k, v in prepass.items() if v['launches'] > 0}
+        if head['ranks'] is not None:
+            out['ranks'] = head['ranks']
+        if other is not None:
+            var.set_hip_precision('f16')
+            ips2, roof2, whole2, extra2 = describe_mode(other, args, world, var, pns)
+            out['modes'] = {'f16': {'value': round(ips2, 3), 'unit': 'images/sec', 'ms_per_step': round(other['dt'] / other['steps'] * 1e3, 3),
+                                    'steps': other['steps'], 'warmup': other['warmup'], 'dtype': 'f16', 'precision': precision['f16'],
+                                    'same_workload_as_headline': True, 'speedup_vs_headline': round(ips2 / ips, 3),
+                                    'roofline': roof2, 'whole_path': whole2, **extra2}}
+            if other['ranks'] is not None:
+                out['modes']['f16']['ranks'] = other['ranks']
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.depth, pns)
         print(json.dumps(out), flush=True)

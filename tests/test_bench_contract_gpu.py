@@ -34,7 +34,21 @@ def test_bench_line_has_the_contract_keys():
         assert k in r, k
     assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and r['peak'] == 157.3 and 0 < r['frac'] < 1
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
-    assert 'cpu_baseline' not in j
+    assert 'cpu_baseline' not in j and 'ranks' not in j
+    # the 16-bit throughput mode, timed in the same process after the f32 region: its own value, steps, dominant kernel and roofline
+    m = j['modes']['f16']
+    assert m['dtype'] == 'f16' and m['steps'] >= 10 and m['warmup'] == 2 and m['value'] > 0 and m['unit'] == 'images/sec'
+    assert abs(m['value'] - 2 / (m['ms_per_step'] * 1e-3)) < 1e-2 * m['value'] and abs(m['speedup_vs_headline'] - m['value'] / j['value']) < 1e-2
+    r16 = m['roofline']
+    assert r16['peak'] == 2500.0 and r16['family'] in ('gemm16', 'conv16h', 'attn16') and 0 < r16['frac'] < 1 and r16['launches'] > 0
+    assert m['whole_path']['peak_tflops'] == 2500.0 and set(m['whole_path']['mfma_time_weighted']['families']) >= {'gemm16_small', 'gemm_small'}
+
+
+def test_bench_line_f16_headline_and_no_modes():
+    j = _run('--no-cpu-baseline', '--dtype', 'f16')
+    assert j['dtype'] == 'f16' and 'modes' not in j and j['roofline']['peak'] == 2500.0
+    j = _run('--no-cpu-baseline', '--no-modes')
+    assert j['dtype'] == 'f32' and 'modes' not in j
 
 
 _RCCL_CHILD = r'''

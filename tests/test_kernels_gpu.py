@@ -95,6 +95,17 @@ def test_timing_table_counts_only_the_selected_families():
     hip.timing_enable(False)
     t = hip.timing_read()
     assert t['conv3x3']['launches'] == 1 and t['conv_small']['launches'] == 2 and t['conv3x3']['flops'] == 2.0 * 64 * 160 * 9 * 32
+    # the 16-bit mode's kernels are counted in families of their own (one arithmetic type = one MFMA peak per family)
+    a16, w16 = torch.randn(512, 128, device='cuda').half(), torch.randn(512, 128, device='cuda').half()
+    o16 = torch.empty(512, 512, device='cuda', dtype=torch.float16)
+    hip.timing_reset(); hip.timing_enable(True)
+    hip.call('gemm_nt_f16', a16, 128, w16, 128, None, o16, 512, 1, 512, 512, 128, 0, None, 0, 0, None, 0, 1, 1, 0, 0, 0)
+    hip.lib().so.varhip_gemm16_force_tile(2)
+    try: hip.call('gemm_nt_f16', a16, 128, w16, 128, None, o16, 512, 1, 512, 512, 128, 0, None, 0, 0, None, 0, 1, 1, 0, 0, 0)
+    finally: hip.lib().so.varhip_gemm16_force_tile(-1)
+    hip.timing_enable(False)
+    t = hip.timing_read()
+    assert t['gemm16_small']['launches'] == 1 and t['gemm16']['launches'] == 1 and t['gemm']['launches'] == 0 and t['gemm_small']['launches'] == 0
 
 
 @pytest.mark.parametrize('M,N,K', [(128, 128, 128), (4, 384, 128), (36, 512, 128), (300, 320, 640), (1152, 1024, 1024), (2048, 3072, 1024), (64, 4096, 256), (1, 128, 32), (130, 40, 8), (9, 128, 9), (25, 33, 25), (70, 70, 13), (70, 50, 64), (3, 52, 96), (200, 17, 32)])
@@ -254,6 +265,21 @@ def test_attn_cached_exact(B2, l, H, curL, Lmax):
     out = np.zeros((B2 * l, C), np.float32)
     (g,), (w,) = both('attn_cached_f32', [q, kc, vc, out, B2, l, H, curL, Lmax], [3])
     check(f'attn l={l} curL={curL}', g, w)
+
+
+@pytest.mark.parametrize('l,curL', [(324, 536), (576, 1112), (1024, 2240)])
+@pytest.mark.parametrize('H', [1, 36])
+def test_attn_cached_exact_at_d36_512_shapes(l, curL, H):
+    """BASELINE.json configs[4] (VAR-d36 512x512: patch_nums up to 32, L = 2240, 36 heads): the three largest scales' (l, curL), which
+    no d16-sized case reaches — 8 to 32 workgroups of queries per head, 17 to 70 key tiles, a 2240-row cache stride — against the oracle, bit for bit"""
+    rng = np.random.default_rng(l + curL + H)
+    B2, Lmax, C = (2 if H == 1 else 1), 2240, 64 * H
+    q = rnd(rng, B2 * l, C, scale=0.6)
+    kc = rnd(rng, B2, H, Lmax, 64, scale=0.5); vc = rnd(rng, B2, H, Lmax, 64)
+    kc[:, :, curL:] = np.nan; vc[:, :, curL:] = np.nan
+    out = np.zeros((B2 * l, C), np.float32)
+    (g,), (w,) = both('attn_cached_f32', [q, kc, vc, out, B2, l, H, curL, Lmax], [3])
+    check(f'attn d36-512 l={l} curL={curL} H={H}', g, w)
 
 
 def test_attn_random_ragged_shapes_exact():
@@ -567,14 +593,34 @@ def test_softmax_rows_exact():
     (g,), (w,) = both('softmax_rows_f32', [x, out, 7, 9, 1.0], [1]); check('softmax rows n=9', g, w)
 
 
-def test_nearest_code_exact():
-    rng = np.random.default_rng(21)
-    z, cb = rnd(rng, 333, 32, scale=1.5), rnd(rng, 4096, 32)
-    cb[77] = cb[5]                                  # an exact tie: first index must win
+@pytest.mark.parametrize('name', ['nearest_code_f32', 'nearest_code_cos_f32'])
+@pytest.mark.parametrize('N,V,Cv', [(333, 4096, 32), (1, 4096, 32), (130, 1000, 32), (4097, 512, 32), (50, 4096, 16), (7, 300, 8)])
+def test_nearest_code_exact(name, N, V, Cv):
+    """f_to_idxBl_or_fhat's arg-min / arg-max (quant.py:151-157), both variants: the MFMA kernel (Cvae = 32: 128 queries per workgroup,
+    512-code shards in LDS; partial last workgroup, partial last shard and block) and the fallback for other widths; exact ties inside a
+    lane's codes, across the two lane halves of a query, across blocks and across shards — the first index must win"""
+    rng = np.random.default_rng(21 + N + V)
+    z, cb = rnd(rng, N, Cv, scale=1.5), rnd(rng, V, Cv)
+    for dup in (9, 77, min(600, V - 1)):                # code 5 again at 9 (other lane half), 77 (another block), 600 (another shard)
+        cb[dup] = cb[5]
     z[0] = cb[77]
-    idx = np.zeros(333, np.int64)
-    (g,), (w,) = both('nearest_code_f32', [z, cb, idx, 333, 4096, 32], [2]); check('nearest_code', g, w)
-    assert g[0] == 5
+    if N > 40: z[40] = cb[5] * 1.0
+    idx = np.zeros(N, np.int64)
+    (g,), (w,) = both(name, [z, cb, idx, N, V, Cv], [2]); check(name, g, w)
+    assert g[0] == 5 and (N <= 40 or g[40] == 5)
+
+
+def test_nearest_code_at_encode_sizes():
+    """every scale of a B=8 256x256 encode (N = 8 * pn^2 up to 2048 rows against the 4096 x 32 codebook), data with many near-ties
+    (queries are codebook rows plus small noise)"""
+    rng = np.random.default_rng(5)
+    cb = rnd(rng, 4096, 32)
+    for pn in (1, 2, 3, 4, 5, 6, 8, 10, 13, 16):
+        N = 8 * pn * pn
+        z = cb[rng.integers(0, 4096, N)] + rnd(rng, N, 32, scale=0.3)
+        idx = np.zeros(N, np.int64)
+        for name in ('nearest_code_f32', 'nearest_code_cos_f32'):
+            (g,), (w,) = both(name, [z, cb, idx, N, 4096, 32], [2]); check(f'{name} pn={pn}', g, w)
 
 
 def test_vm_exp_matches_cpu_bit_for_bit():

@@ -193,7 +193,7 @@ extern "C" int varhip_attn_cached_f16(const void* q, const void* kcache, const v
                                       int B2, int l, int H, int curL, int Lmax, varhip_stream_t stream) {
     if (B2 <= 0 || l <= 0 || H <= 0 || curL <= 0 || curL > Lmax) return VARHIP_EINVAL;
     if (B2 > 65535 || H > 65535 || (((uintptr_t)q | (uintptr_t)kcache | (uintptr_t)vcache | (uintptr_t)out) & 15)) return VARHIP_EINVAL;
-    VhScope sc(VH_FAM_ATTN, (hipStream_t)stream, 4.0 * B2 * H * (double)l * curL * 64, 2.0 * B2 * H * (2.0 * curL * 64 + 2.0 * l * 64));
+    VhScope sc(VH_FAM_ATTN16, (hipStream_t)stream, 4.0 * B2 * H * (double)l * curL * 64, 2.0 * B2 * H * (2.0 * curL * 64 + 2.0 * l * 64));
     const int nw = attn16_waves(l);
     dim3 grid((l + nw * 32 - 1) / (nw * 32), H, B2);
     hipStream_t s = (hipStream_t)stream;

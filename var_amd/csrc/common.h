@@ -52,6 +52,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define VH_FAM_OTHER 7
 #define VH_FAM_GEMM_SMALL 8
 #define VH_FAM_CONV_SMALL 9
+// the 16-bit mode's kernels have families of their own: one arithmetic type (one MFMA peak) per family, and the three that can dominate a
+// step map to exactly one kernel symbol each (k_gemm16<8,4,2,4>, k_conv16h<5,32>, k_attn16<NW>)
+#define VH_FAM_GEMM16 10
+#define VH_FAM_GEMM16_SMALL 11
+#define VH_FAM_CONV16H 12
+#define VH_FAM_CONV16_SMALL 13
+#define VH_FAM_ATTN16 14
 
 // ---- timing table (timing.cpp) ------------------------------------------------------------------------------------
 int vh_timing_on(int fam);

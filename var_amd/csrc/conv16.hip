@@ -467,19 +467,28 @@ static int launch_conv16(Conv16P& p, int nz, hipStream_t s) {
 }
 static int g_conv16_force_wm = 0;                                 // 0: by size; 2 / 4: experiments (tools/bench_kernels.py, tests)
 extern "C" int varhip_conv16_force_tile(int wm) { g_conv16_force_wm = (wm == 2 || wm == 4 || wm == 8) ? wm : 0; return 0; }
-static int dispatch_conv16(Conv16P& p, int nz, hipStream_t s) {
+// which kernel takes a launch: 1 / 2 = the halo-patch kernel with 8x32 / 16x16 patches, 3 = 256-pixel tiles, 0 = 128-pixel tiles
+static int pick_conv16(const Conv16P& p, int nz) {
     // the halo-patch kernel: plain 3x3 convs on maps that tile into 8x32 or 16x16 patches, once there is a workgroup for every CU
     if (!p.phase && p.out_mode == 0 && g_conv16_force_wm != 2 && g_conv16_force_wm != 4 && (p.N % 160 == 0 || p.N % 128 == 0)
         && (int64_t)p.H * p.Wd * p.Cin * 2 < (1ll << 31)
         && (g_conv16_force_wm == 8 || (int64_t)(p.M / 256) * (p.N / (p.N % 160 == 0 ? 160 : 128)) >= 256)) {
         const int64_t wgs = (int64_t)(p.M / 256) * (p.N / (p.N % 160 == 0 ? 160 : 128));
         const bool w32 = (p.Wd % 32 == 0) && (p.H % 8 == 0), w16 = (p.Wd % 16 == 0) && (p.H % 16 == 0) && (g_conv16_force_wm == 8 || wgs >= 512);
-        if (w32) return p.N % 160 == 0 ? launch_conv16h<5, 32>(p, s) : launch_conv16h<4, 32>(p, s);
-        if (w16) return p.N % 160 == 0 ? launch_conv16h<5, 16>(p, s) : launch_conv16h<4, 16>(p, s);
+        if (w32) return 1;
+        if (w16) return 2;
     }
     // 256-pixel tiles (8 waves, two workgroups per CU) once they give every CU a workgroup
     const int64_t big_wgs = (int64_t)((p.M + 255) / 256) * ((p.N + 159) / 160) * nz;
-    const bool big = g_conv16_force_wm ? g_conv16_force_wm == 4 : big_wgs >= 256;
+    return (g_conv16_force_wm ? g_conv16_force_wm == 4 : big_wgs >= 256) ? 3 : 0;
+}
+// timing family of a launch: k_conv16h<5,32> (the decoder's dominant symbol) alone in VH_FAM_CONV16H
+static int conv16_family(const Conv16P& p, int nz) { return (pick_conv16(p, nz) == 1 && p.N % 160 == 0) ? VH_FAM_CONV16H : VH_FAM_CONV16_SMALL; }
+static int dispatch_conv16(Conv16P& p, int nz, hipStream_t s) {
+    const int pick = pick_conv16(p, nz);
+    if (pick == 1) return p.N % 160 == 0 ? launch_conv16h<5, 32>(p, s) : launch_conv16h<4, 32>(p, s);
+    if (pick == 2) return p.N % 160 == 0 ? launch_conv16h<5, 16>(p, s) : launch_conv16h<4, 16>(p, s);
+    const bool big = pick == 3;
     if (p.N % 160 == 0) return big ? launch_conv16<5, 3, 4, 2>(p, nz, s) : launch_conv16<5, 4, 2>(p, nz, s);
     if (p.N % 128 == 0) return big ? launch_conv16<4, 3, 4, 2>(p, nz, s) : launch_conv16<4, 4, 2>(p, nz, s);
     if (p.N % 64 == 0) return launch_conv16<2, 4, 2>(p, nz, s);
@@ -508,7 +517,7 @@ extern "C" int varhip_conv3x3_nhwc_f16(const void* in, const void* w, const floa
     p.in = (const _Float16*)in; p.w = (const _Float16*)w; p.bias = bias; p.out = out; p.resid = (const _Float16*)resid; p.gn_part = gn_part;
     p.M = B * H * W; p.N = Cout; p.K = 9 * Cin; p.H = H; p.Wd = W; p.Cin = Cin; p.phase = 0; p.out_mode = out_mode; p.sW = 0;
     const double npix = (double)B * H * W;
-    VhScope scope((Cout % 160 == 0) ? VH_FAM_CONV : VH_FAM_CONV_SMALL, (hipStream_t)stream, 2.0 * npix * Cout * 9.0 * Cin,
+    VhScope scope(conv16_family(p, 1), (hipStream_t)stream, 2.0 * npix * Cout * 9.0 * Cin,
                   2.0 * (npix * Cin + npix * Cout * (resid ? 2.0 : 1.0) + 9.0 * Cin * Cout));
     return dispatch_conv16(p, 1, (hipStream_t)stream);
 }
@@ -528,7 +537,7 @@ extern "C" int varhip_upconv_phase_f16(const void* in, const void* w_phase, cons
     p.M = B * (H / 2) * (W / 2); p.N = Cout; p.K = 4 * Cin; p.H = H / 2; p.Wd = W / 2; p.Cin = Cin; p.phase = 1; p.out_mode = 0;
     p.sW = (int64_t)Cout * 4 * Cin;
     const double npix = (double)B * H * W;
-    VhScope scope((Cout % 160 == 0) ? VH_FAM_CONV : VH_FAM_CONV_SMALL, (hipStream_t)stream, 2.0 * npix * Cout * 4.0 * Cin,
+    VhScope scope(conv16_family(p, 4), (hipStream_t)stream, 2.0 * npix * Cout * 4.0 * Cin,
                   2.0 * (npix * Cin / 4.0 + npix * Cout + 16.0 * Cin * Cout));
     return dispatch_conv16(p, 4, (hipStream_t)stream);
 }

@@ -392,7 +392,7 @@ extern "C" int varhip_gemm_nt_f16(const void* A, int64_t lda, const void* W, int
     p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.ldr = ldr; p.ldg = ldg; p.sA = sA; p.sW = sW; p.sO = sO;
     p.M = M; p.N = N; p.K = K; p.epi = epi; p.rows_per_group = rows_per_group > 0 ? rows_per_group : 1; p.out_f16 = out_f16; p.resid_f16 = resid_f16;
     const int pick = pick_tile16(M, N, batch, epi == VARHIP_EPI_RESID && !resid_f16);
-    VhScope scope(pick == 2 ? VH_FAM_GEMM : VH_FAM_GEMM_SMALL, (hipStream_t)stream, 2.0 * M * N * (double)K * batch,
+    VhScope scope(pick == 2 ? VH_FAM_GEMM16 : VH_FAM_GEMM16_SMALL, (hipStream_t)stream, 2.0 * M * N * (double)K * batch,
                   batch * (2.0 * ((double)M * K + (double)N * K) + (out_f16 ? 2.0 : 4.0) * (double)M * N));
     if (pick == 2) return launch16<8, 4, 2, 4>(p, batch, (hipStream_t)stream);
     return pick == 0 ? launch16<4, 4>(p, batch, (hipStream_t)stream) : launch16<2, 2>(p, batch, (hipStream_t)stream);
@@ -412,7 +412,7 @@ extern "C" int varhip_gemm_qkv_f16(const void* A, int64_t lda, const void* W, in
     p.q_smul = scale_mul; p.q_out = (_Float16*)q_out; p.q_kc = (_Float16*)kcache; p.q_vc = (_Float16*)vcache; p.q_plain = plain_scale;
     p.q_l2 = l2norm; p.q_l = l; p.q_pos0 = pos0; p.q_Lmax = Lmax;
     const int pick = pick_tile16(M, 3 * C, 1);
-    VhScope scope(pick == 2 ? VH_FAM_GEMM : VH_FAM_GEMM_SMALL, (hipStream_t)stream, 2.0 * M * 3.0 * C * (double)K, 2.0 * ((double)M * K + 3.0 * C * K + 3.0 * M * C));
+    VhScope scope(pick == 2 ? VH_FAM_GEMM16 : VH_FAM_GEMM16_SMALL, (hipStream_t)stream, 2.0 * M * 3.0 * C * (double)K, 2.0 * ((double)M * K + 3.0 * C * K + 3.0 * M * C));
     if (pick == 2) return launch16<8, 4, 2, 4>(p, 1, (hipStream_t)stream);
     return pick == 0 ? launch16<4, 4>(p, 1, (hipStream_t)stream) : launch16<2, 4>(p, 1, (hipStream_t)stream);
 }

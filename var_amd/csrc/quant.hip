@@ -264,7 +264,111 @@ extern "C" int varhip_token_select_i64(const uint8_t* keep, const int64_t* gt, c
     return vh_launch_status();
 }
 
-// nearest code: one workgroup per z row; thread t scores codes t, t+256, ...; (distance, index) min with first-index ties
+// ---- nearest code (VectorQuantizer2.f_to_idxBl_or_fhat, reference quant.py:151-157) --------------------------------------------------
+// k_nearest_mfma: 128 queries per workgroup (32 per wave), the codebook streamed through LDS in shards of 512 codes (64 KB of fp32 rows,
+// staged once per workgroup and shard instead of once per QUERY as the first kernel did: 43 520 workgroups x 512 KB of L2 reads at B=64).
+// The scores z.e are the reference's own GEMM (addmm_ / matmul) and run on the fp32 MFMA: v_mfma_f32_32x32x2_f32 with lane half kk
+// supplying channel 2s + kk in step s is ONE fma chain in ascending channel order starting from 0 — bit for bit the oracle's
+// `dot = fma(z[c], e[c], dot)` loop.  Per lane: query = lane & 31, 16 codes of every 32-code block (accumulator register
+// 4g + j <-> code 8g + 4h + j, h = lane >> 5), scanned in ascending code order with a strict comparison (first index wins a tie); the two
+// lane halves of a query are merged by (value, index).  COS = false: d = (|z|^2 + |e|^2) + (-2 z.e), argmin.  COS = true (using_znorm):
+// argmax of the chain over (z[c] / max(|z|, 1e-12)) * (e[c] / max(|e|, 1e-12)), every factor rounded as F.normalize rounds it.
+#define NC_SHARD 512
+#define NC_ROWB 144            // bytes per staged code row: 16 even channels | 16 odd channels | 16 pad (ds_read_b128 of 16 rows: conflict-free)
+template <bool COS>
+__global__ void __launch_bounds__(256, 2) k_nearest_mfma(const float* __restrict__ z, const float* __restrict__ codebook, int64_t* __restrict__ idx_out, int N, int V) {
+    constexpr int CV = 32;
+    extern __shared__ __attribute__((aligned(16))) char nc_smem[];
+    float* s_ee = (float*)(nc_smem + NC_SHARD * NC_ROWB);              // |e|^2 of the staged codes
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ql = lane & 31, kk = lane >> 5;
+    const int64_t q0 = (int64_t)blockIdx.x * 128 + wave * 32;
+    const int64_t q = (q0 + ql < N) ? q0 + ql : (int64_t)N - 1;
+    // this lane's operand of the 16 MFMA steps: channels kk, 2 + kk, 4 + kk, ... of its query
+    float zf[CV / 2], zz = 0.f;
+    {
+        float zr[CV];
+#pragma unroll
+        for (int c4 = 0; c4 < CV / 4; ++c4) { const f32x4 t = *(const f32x4*)(z + q * CV + c4 * 4); zr[4 * c4] = t[0]; zr[4 * c4 + 1] = t[1]; zr[4 * c4 + 2] = t[2]; zr[4 * c4 + 3] = t[3]; }
+#pragma unroll
+        for (int c = 0; c < CV; ++c) zz = vm_fma(zr[c], zr[c], zz);
+        const float zn = vm_max(vm_sqrt(zz), 1e-12f);
+#pragma unroll
+        for (int s2 = 0; s2 < CV / 2; ++s2) { const float v = z[q * CV + 2 * s2 + kk]; zf[s2] = COS ? v / zn : v; }      // (re-read: a register array indexed by kk would go to scratch)
+    }
+    float bd = COS ? -INFINITY : INFINITY; int bi = 0;
+    for (int v0 = 0; v0 < V; v0 += NC_SHARD) {
+        __syncthreads();                                               // the previous shard has been read by every wave
+        for (int r = tid; r < NC_SHARD; r += 256) {                    // stage: one thread per code row, channels de-interleaved
+            const int v = v0 + r;
+            float er[CV];
+            if (v < V) {
+#pragma unroll
+                for (int c4 = 0; c4 < CV / 4; ++c4) { const f32x4 t = *(const f32x4*)(codebook + (int64_t)v * CV + c4 * 4); er[4 * c4] = t[0]; er[4 * c4 + 1] = t[1]; er[4 * c4 + 2] = t[2]; er[4 * c4 + 3] = t[3]; }
+            } else {
+#pragma unroll
+                for (int c = 0; c < CV; ++c) er[c] = 0.f;
+            }
+            float ee = 0.f;
+#pragma unroll
+            for (int c = 0; c < CV; ++c) ee = vm_fma(er[c], er[c], ee);
+            if (COS) {
+                const float en = vm_max(vm_sqrt(ee), 1e-12f);
+#pragma unroll
+                for (int c = 0; c < CV; ++c) er[c] = er[c] / en;
+            }
+            float* row = (float*)(nc_smem + r * NC_ROWB);
+#pragma unroll
+            for (int c4 = 0; c4 < CV / 8; ++c4) {
+                *(f32x4*)(row + 4 * c4) = f32x4{er[8 * c4], er[8 * c4 + 2], er[8 * c4 + 4], er[8 * c4 + 6]};
+                *(f32x4*)(row + CV / 2 + 4 * c4) = f32x4{er[8 * c4 + 1], er[8 * c4 + 3], er[8 * c4 + 5], er[8 * c4 + 7]};
+            }
+            s_ee[r] = ee;
+        }
+        __syncthreads();
+        const int nblk = ((V - v0 < NC_SHARD ? V - v0 : NC_SHARD) + 31) / 32;
+        for (int blk = 0; blk < nblk; ++blk) {
+            const float* er = (const float*)(nc_smem + (blk * 32 + ql) * NC_ROWB) + kk * (CV / 2);      // A operand: code row ql of the block, this half's channels
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int c4 = 0; c4 < CV / 8; ++c4) {
+                const f32x4 ef = *(const f32x4*)(er + 4 * c4);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ef[u], zf[4 * c4 + u], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cb = blk * 32 + 8 * g + 4 * kk;              // first of this lane's four codes of the group (shard-local)
+                const f32x4 e4 = *(const f32x4*)(s_ee + cb);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int code = v0 + cb + j;
+                    if (COS) { const float d = acc[4 * g + j]; if (d > bd && code < V) { bd = d; bi = code; } }
+                    else { const float d = (zz + e4[j]) + (-2.0f * acc[4 * g + j]); if (d < bd && code < V) { bd = d; bi = code; } }
+                }
+            }
+        }
+    }
+    {   // the other half of the query's codes: smaller distance (larger cosine) wins, the smaller index on a tie
+        const float od = __shfl_xor(bd, 32, 64); const int oi = __shfl_xor(bi, 32, 64);
+        const bool better = COS ? (od > bd) : (od < bd);
+        if (better || (od == bd && oi < bi)) { bd = od; bi = oi; }
+    }
+    if (kk == 0 && q0 + ql < N) idx_out[q0 + ql] = bi;
+}
+template <bool COS>
+static int launch_nearest_mfma(const float* z, const float* codebook, int64_t* idx_out, int N, int V, hipStream_t stream) {
+    constexpr size_t lds = (size_t)NC_SHARD * NC_ROWB + NC_SHARD * 4;
+    auto kfn = k_nearest_mfma<COS>;
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+    hipLaunchKernelGGL(kfn, dim3((unsigned)((N + 127) / 128)), dim3(256), lds, stream, z, codebook, idx_out, N, V);
+    return vh_launch_status();
+}
+
+// fallback for codebooks the MFMA kernel does not take (Cvae != 32): one workgroup per z row; thread t scores codes t, t+256, ...;
+// (distance, index) min with first-index ties
 __global__ void __launch_bounds__(256) k_nearest_code(const float* __restrict__ z, const float* __restrict__ codebook, int64_t* __restrict__ idx_out, int V, int Cv) {
     __shared__ float sz[64];
     __shared__ float s_d[4]; __shared__ int s_i[4];
@@ -296,7 +400,8 @@ __global__ void __launch_bounds__(256) k_nearest_code(const float* __restrict__ 
 extern "C" int varhip_nearest_code_f32(const float* z, const float* codebook, int64_t* idx_out, int N, int V, int Cv, varhip_stream_t stream) {
     if (N < 0 || V <= 0 || Cv <= 0 || Cv > 64) return VARHIP_EINVAL;
     if (N == 0) return 0;
-    VhScope sc(VH_FAM_OTHER, (hipStream_t)stream, 4.0 * N * (double)V * Cv, 4.0 * ((double)N * Cv + (double)V * Cv));
+    VhScope sc(VH_FAM_OTHER, (hipStream_t)stream, 4.0 * N * (double)V * Cv, 4.0 * ((double)N * Cv + (double)V * Cv) + 8.0 * N);
+    if (Cv == 32 && (((uintptr_t)z | (uintptr_t)codebook) & 15) == 0) return launch_nearest_mfma<false>(z, codebook, idx_out, N, V, (hipStream_t)stream);
     hipLaunchKernelGGL(k_nearest_code, dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream, z, codebook, idx_out, V, Cv);
     return vh_launch_status();
 }
@@ -337,7 +442,8 @@ __global__ void __launch_bounds__(256) k_nearest_code_cos(const float* __restric
 extern "C" int varhip_nearest_code_cos_f32(const float* z, const float* codebook, int64_t* idx_out, int N, int V, int Cv, varhip_stream_t stream) {
     if (N < 0 || V <= 0 || Cv <= 0 || Cv > 64) return VARHIP_EINVAL;
     if (N == 0) return 0;
-    VhScope sc(VH_FAM_OTHER, (hipStream_t)stream, 4.0 * N * (double)V * Cv, 4.0 * ((double)N * Cv + (double)V * Cv));
+    VhScope sc(VH_FAM_OTHER, (hipStream_t)stream, 4.0 * N * (double)V * Cv, 4.0 * ((double)N * Cv + (double)V * Cv) + 8.0 * N);
+    if (Cv == 32 && (((uintptr_t)z | (uintptr_t)codebook) & 15) == 0) return launch_nearest_mfma<true>(z, codebook, idx_out, N, V, (hipStream_t)stream);
     hipLaunchKernelGGL(k_nearest_code_cos, dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream, z, codebook, idx_out, V, Cv);
     return vh_launch_status();
 }

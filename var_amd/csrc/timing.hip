@@ -72,7 +72,8 @@ int varhip_timing_read(double* ms, double* flops, double* bytes, int64_t* launch
 }
 
 const char* varhip_timing_name(int f) {
-    static const char* names[VARHIP_NFAM] = {"gemm", "conv3x3", "attn", "sampler", "ln", "qkv_prep", "gn", "other", "gemm_small", "conv_small"};
+    static const char* names[VARHIP_NFAM] = {"gemm", "conv3x3", "attn", "sampler", "ln", "qkv_prep", "gn", "other", "gemm_small", "conv_small",
+                                               "gemm16", "gemm16_small", "conv16h", "conv16_small", "attn16"};
     return (f >= 0 && f < VARHIP_NFAM) ? names[f] : "?";
 }
 

@@ -74,7 +74,7 @@ def conv_gn_blocks(H, W, Cout, phase=False) -> int:
 
 
 # ---- timing table --------------------------------------------------------------------------------------------------
-NFAM = 10            # VARHIP_NFAM of include/var_hip.h
+NFAM = 15            # VARHIP_NFAM of include/var_hip.h
 
 
 def timing_enable(on: bool, families=None):

@@ -24,11 +24,12 @@ def shard_range(B_total: int, rank: int, world: int):
 
 def sample_sharded(var, B_total: int, label_B: torch.Tensor, g_seed: Optional[int], cfg: float = 1.5, top_k: int = 0, top_p: float = 0.0,
                    rng_mode: str = 'exact', gather: bool = True, sample_fn: Optional[Callable] = None,
-                   rank: Optional[int] = None, world: Optional[int] = None) -> torch.Tensor:
+                   rank: Optional[int] = None, world: Optional[int] = None, gather_events: Optional[list] = None) -> torch.Tensor:
     """Sample `B_total` images split evenly over the ranks; returns all images on every rank (gather=True) or the local shard.
 
     `label_B`: the GLOBAL int64 label vector (same on every rank).  `sample_fn(B_local, labels_local, noise_fn)` defaults to the
-    HIP engine; the CPU tests of the sharding logic substitute a stand-in."""
+    HIP engine; the CPU tests of the sharding logic substitute a stand-in.  `gather_events`: a list that receives one (start, end) pair of
+    CUDA events per call around the all-gather."""
     rank = dist.get_rank() if rank is None else rank
     world = dist.get_world_size() if world is None else world
     lo, hi = shard_range(B_total, rank, world)
@@ -56,4 +57,13 @@ def sample_sharded(var, B_total: int, label_B: torch.Tensor, g_seed: Optional[in
         img = sample_fn(B_local, labels_local, noise_fn)
     if not gather or world == 1:
         return img
-    return dist.allgather(img, cat=True)
+    if gather_events is None or not img.is_cuda:
+        return dist.allgather(img, cat=True)
+    # bench.py: HIP events around the collective on the stream it is enqueued on (diagnosis of a scaling run: a rank that arrives early
+    # waits inside the all-gather, so max - min over ranks of this time is the arrival skew)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    out = dist.allgather(img, cat=True)
+    b.record()
+    gather_events.append((a, b))
+    return out
