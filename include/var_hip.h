@@ -124,6 +124,9 @@ int varhip_adaln_block_f32(float* x, float* x2, float* xn, float* q, float* att,
  * Constraint: V % 256 == 0, V <= 8192, 0 <= top_k <= V. */
 int varhip_cfg_sample_f32(const float* logits, const float* noise, int64_t* idx_out, float* masked_out,
                           int B, int l, int V, double t_cfg, int top_k, double top_p, varhip_stream_t stream);
+/* test hook: 1 = every top-p cut is decided by the sequential fp64 walk (the definition); 0 (default) = by a parallel prefix sum wherever
+ * that provably gives the same cut, by the walk otherwise.  Same results either way. */
+int varhip_sampler_force_walk(int on);
 
 /* ---- multi-scale quantizer step ---------------------------------------------------------------------------
  * Feature maps are kept channels-last: f_hat[B][P][P][Cv].

@@ -120,6 +120,46 @@ def test_gemm16_at_d30_d36_widths_every_tile(tile, N, K, mode):
     assert bool((err <= tol).all()), f'{mode} {M}x{N}x{K} tile {tile}: {int((err > tol).sum())} outside tolerance, max err {float(err.max()):.3e}'
 
 
+def test_gemm16_row_split_launches_are_invisible():
+    """a GEMM whose last round of 256x256 tiles would be under 70 % full goes out as two launches over row ranges (the rows that fill whole
+    rounds on the 256x256 kernel, the rest on a small-tile kernel): same bits as a single-kernel run, right against float64; the row offset
+    reaches gamma's row groups (rows_per_group = 300 straddles the cut) and the q/k/v epilogue's (image, position) decode (l = 100)"""
+    hip = _hip()
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 38400, 512, 64                       # 150 x 2 = 300 tiles: one full round (32768 rows) + 5632 rows
+    A = (torch.randn(M, K, generator=g) * 0.7).half().cuda(); W = (torch.randn(N, K, generator=g) * 0.2).half().cuda()
+    bias = (torch.randn(N, generator=g) * 0.2).cuda(); resid = torch.randn(M, N, generator=g).cuda(); gamma = (torch.randn(128, N, generator=g) * 0.5).cuda()
+    def run(t, epi, out16):
+        out = torch.empty(M, N, dtype=torch.float16 if out16 else torch.float32, device='cuda')
+        hip.lib().so.varhip_gemm16_force_tile(t)
+        try: hip.call('gemm_nt_f16', A, K, W, K, bias, out, N, int(out16), M, N, K, epi, resid if epi == 2 else None, N, 0, gamma if epi == 2 else None, N, 300, 1, 0, 0, 0)
+        finally: hip.lib().so.varhip_gemm16_force_tile(-1)
+        return out
+    hip.timing_reset(); hip.timing_enable(True)
+    auto_res = run(-1, 2, False)
+    hip.timing_enable(False)
+    t = hip.timing_read()
+    assert t['gemm16']['launches'] == 1 and t['gemm16_small']['launches'] == 1, 'expected one 256x256 launch + one small-tile launch'
+    assert t['gemm16']['flops'] == 2.0 * 32768 * N * K and t['gemm16_small']['flops'] == 2.0 * 5632 * N * K
+    assert torch.equal(auto_res, run(1, 2, False)) and torch.equal(run(-1, 1, True), run(1, 1, True))
+    ref = resid.double().cpu() + (A.double().cpu() @ W.double().cpu().T + bias.double().cpu()) * gamma.double().cpu().repeat_interleave(300, dim=0)[:M]
+    assert float((auto_res.double().cpu() - ref).abs().max()) <= 1e-4
+    # q/k/v: H = 4 heads (N = 768: 3 column tiles), l = 100, B2 = 256 -> 100 x 3 = 300 tiles, the cut at row 21760 falls inside image 217
+    B2, l, H, pos0, Lmax = 256, 100, 4, 7, 120
+    C = H * 64; M2 = B2 * l
+    A2 = torch.randn(M2, C, generator=g).half().cuda(); W2 = (torch.randn(3 * C, C, generator=g) * (1.0 / C ** 0.5)).half().cuda()
+    b2 = (torch.randn(3 * C, generator=g) * 0.1).cuda(); smul = (torch.randn(H, generator=g) * 0.3 + 1.4).cuda()
+    outs = []
+    for tile in (-1, 1):
+        q = torch.empty(M2, C, dtype=torch.float16, device='cuda'); kc = torch.zeros(B2, H, Lmax, 64, dtype=torch.float16, device='cuda'); vc = torch.zeros_like(kc)
+        hip.lib().so.varhip_gemm16_force_tile(tile)
+        try: hip.call('gemm_qkv_f16', A2, C, W2, C, b2, M2, C, C, smul, 0.125, 1, q, kc, vc, B2, l, H, pos0, Lmax)
+        finally: hip.lib().so.varhip_gemm16_force_tile(-1)
+        outs.append((q, kc, vc))
+    for a, b in zip(*outs): assert torch.equal(a, b)
+    assert float(outs[0][1][:, :, :pos0].abs().max()) == 0 and float(outs[0][1][:, :, pos0 + l:].abs().max()) == 0 and float(outs[0][1][217].abs().max()) > 0
+
+
 @pytest.mark.parametrize('B2,l,H,pos0,l2', [(4, 9, 2, 5, 1), (2, 64, 4, 91, 1), (3, 25, 16, 0, 0), (4, 100, 4, 10, 1), (6, 50, 8, 3, 0),
                                             (2, 81, 30, 30, 1), (2, 169, 36, 55, 1)])       # the head counts / widths of VAR-d30 and VAR-d36
 def test_gemm_qkv16_against_float64(B2, l, H, pos0, l2):
@@ -139,7 +179,7 @@ def test_gemm_qkv16_against_float64(B2, l, H, pos0, l2):
         hip.call('gemm_qkv_f16', A.cuda(), K, W.cuda(), K, bias.cuda(), M, C, K, smul.cuda(), 0.125, l2, q2, kc2, vc2, B2, l, H, pos0, Lmax)
     finally:
         hip.lib().so.varhip_gemm16_force_tile(-1)
-    assert torch.equal(vc, vc2)                                   # v rows: no normalisation, identical bits; q / k: the sum of squares is taken in another order
+    assert torch.equal(vc, vc2) and torch.equal(q, q2) and torch.equal(kc, kc2)      # every tile takes the head's sum of squares in the same order: identical bits
     ref = (A.double() @ W.double().T + bias.double()).view(B2, l, 3, H, 64)
     rq, rk, rv = ref[:, :, 0], ref[:, :, 1], ref[:, :, 2]
     if l2:

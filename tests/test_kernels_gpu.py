@@ -307,10 +307,35 @@ def test_attn_peaked_rows():
     check('attn peaked', g, w)
 
 
+@pytest.fixture(params=[0, 1], ids=['parallel_cut', 'walk'])
+def sampler_mode(request):
+    """the sampler decides the top-p cut by a parallel prefix sum wherever that provably equals the sequential fp64 walk (the definition) and by
+    the walk itself otherwise; the test hook forces the walk everywhere — both must reproduce the oracle bit for bit"""
+    _, hip = _setup()
+    hip.lib().so.varhip_sampler_force_walk(request.param)
+    yield request.param
+    hip.lib().so.varhip_sampler_force_walk(0)
+
+
+def test_cfg_sample_cut_exactly_on_the_threshold(sampler_mode):
+    """all logits equal: every probability is exactly 1/V and the running sum j/V is exact; top_p is chosen so that 1 - top_p IS such a value
+    (100/4096): the entry whose running sum equals the threshold is removed ('<='), the next one is not.  Second case: the threshold half
+    an ulp-of-float above a reachable sum, and a threshold no sum reaches before the last entry (everything but the largest goes)."""
+    V, B, l = 4096, 1, 3
+    rng = np.random.default_rng(3)
+    noise = rng.exponential(1.0, (B * l, V)).astype(np.float32)
+    lg = np.full((2 * B * l, V), 0.75, np.float32)
+    for top_p in (1.0 - 100.0 / 4096.0, 1.0 - 100.5 / 4096.0, 1.0 - 4095.0 / 4096.0, 1e-9):
+        idx = np.zeros(B * l, np.int64); masked = np.zeros((B * l, V), np.float32)
+        (gi, gm), (wi, wm) = both('cfg_sample_f32', [lg, noise, idx, masked, B, l, V, 0.0, 0, top_p], [2, 3])
+        check(f'threshold cut top_p={top_p} kept-set', np.isfinite(gm), np.isfinite(wm)); check('threshold cut tokens', gi, wi)
+    assert int(np.isfinite(wm).sum(1).min()) >= 1
+
+
 @pytest.mark.parametrize('B,l,V,t,top_k,top_p,scale', [(2, 5, 4096, 0.75, 900, 0.96, 2.5), (2, 5, 4096, 0.0, 0, 0.0, 2.5), (3, 4, 4096, 1.5, 1, 0.0, 2.5),
                                                        (2, 5, 4096, 0.3, 0, 0.5, 2.5), (2, 3, 4096, 4.0, 50, 0.999, 8.0), (1, 7, 512, 1.0, 100, 0.9, 2.0),
                                                        (1, 2, 8192, 0.5, 8192, 0.0001, 3.0), (2, 64, 4096, 1.5, 900, 0.96, 2.0)])
-def test_cfg_sample_exact(B, l, V, t, top_k, top_p, scale):
+def test_cfg_sample_exact(B, l, V, t, top_k, top_p, scale, sampler_mode):
     rng = np.random.default_rng(V + l + top_k)
     logits = rnd(rng, 2 * B * l, V, scale=scale)
     noise = rng.exponential(1.0, (B * l, V)).astype(np.float32)
@@ -323,7 +348,7 @@ def test_cfg_sample_exact(B, l, V, t, top_k, top_p, scale):
 
 @pytest.mark.parametrize('V,top_k,top_p,n_above,n_tie', [(4096, 900, 0.96, 500, 2000), (4096, 900, 0.3, 899, 3197), (4096, 900, 0.96, 0, 4096),
                                                          (768, 0, 0.9, 0, 0), (4096, 100, 0.999, 99, 300)])
-def test_cfg_sample_tie_crowd_beyond_sort_buffer(V, top_k, top_p, n_above, n_tie):
+def test_cfg_sample_tie_crowd_beyond_sort_buffer(V, top_k, top_p, n_above, n_tie, sampler_mode):
     """more exact ties with the k-th value than the kernel's sort buffer holds (cap = pow2 >= top_k): the tie group is walked in
     index order unsorted.  Also a vocabulary that is not a power of two.  t = 0, unconditional half zero: x == cond exactly."""
     rng = np.random.default_rng(V + n_tie)
@@ -347,7 +372,7 @@ def test_cfg_sample_tie_crowd_beyond_sort_buffer(V, top_k, top_p, n_above, n_tie
         assert np.isfinite(wm).sum(axis=1).min() >= 1
 
 
-def test_cfg_sample_random_quantised_logits_exact():
+def test_cfg_sample_random_quantised_logits_exact(sampler_mode):
     """14 seeded random sampler configurations on logits rounded to a coarse grid (exact ties everywhere: at the top-k threshold,
     inside the top-p walk, at the arg-max), several vocabulary sizes, t != 0 so the CFG combine creates the ties' values"""
     rs = np.random.default_rng(99)
@@ -365,7 +390,7 @@ def test_cfg_sample_random_quantised_logits_exact():
         check(f'sampler random #{case} tokens', gi, wi)
 
 
-def test_cfg_sample_ties_and_golden(golden_dir):
+def test_cfg_sample_ties_and_golden(golden_dir, sampler_mode):
     """rows full of exact ties, and the reference's own sampler fixtures (tests/golden/sampler.npz) straight through the HIP kernel"""
     import json
     z = np.load(f'{golden_dir}/sampler.npz')

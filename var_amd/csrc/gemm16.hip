@@ -21,6 +21,8 @@ struct Gemm16P {
     const _Float16* A; const _Float16* W; const float* bias; void* out; const void* resid; const float* gamma;
     int64_t lda, ldw, ldo, ldr, ldg, sA, sW, sO;
     int M, N, K, epi, rows_per_group, out_f16, resid_f16;
+    int m_base;                // rows of the GEMM in front of this launch (a GEMM may be issued as two launches over row ranges): A / out / resid are pre-offset, gamma's row
+                               // group and the q/k/v epilogue's (image, position) use the absolute row m_base + m
     int tilesM, tilesN;
     // epi == 3: fused q/k/v epilogue (N = 3C, head_dim 64)
     const float* q_smul; _Float16* q_out; _Float16* q_kc; _Float16* q_vc; float q_plain; int q_l2, q_l, q_pos0, q_Lmax;
@@ -214,15 +216,16 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) k_gemm16(Gemm16P p) {
                             v = v * ((sect == 0 ? sm : 1.0f) / vm_max(vm_sqrt(ss), 1e-12f));
                         } else if (!p.q_l2 && sect == 0) v = v * p.q_plain;
                         _Float16* dst;
-                        if (sect == 0) dst = p.q_out + (int64_t)m * Cq + head * 64;
-                        else { const int bb = m / p.q_l, t = m - bb * p.q_l; dst = (sect == 1 ? p.q_kc : p.q_vc) + (((int64_t)bb * Hh + head) * p.q_Lmax + p.q_pos0 + t) * 64; }
+                        const int ma = p.m_base + m;
+                        if (sect == 0) dst = p.q_out + (int64_t)ma * Cq + head * 64;
+                        else { const int bb = ma / p.q_l, t = ma - bb * p.q_l; dst = (sect == 1 ? p.q_kc : p.q_vc) + (((int64_t)bb * Hh + head) * p.q_Lmax + p.q_pos0 + t) * 64; }
                         h4 o; o[0] = (_Float16)v[0]; o[1] = (_Float16)v[1]; o[2] = (_Float16)v[2]; o[3] = (_Float16)v[3];
                         *(h4*)(dst + (lane & 15) * 4) = o;
                         continue;
                     }
                     if (p.epi == VARHIP_EPI_GELU) { v[0] = vh16_gelu(v[0]); v[1] = vh16_gelu(v[1]); v[2] = vh16_gelu(v[2]); v[3] = vh16_gelu(v[3]); }
                     else if (p.epi == VARHIP_EPI_RESID) {
-                        if (p.gamma) v = v * *(const f32x4*)(p.gamma + (int64_t)(m / p.rows_per_group) * p.ldg + n);
+                        if (p.gamma) v = v * *(const f32x4*)(p.gamma + (int64_t)((p.m_base + m) / p.rows_per_group) * p.ldg + n);
                         if (p.resid_f16) { const h4 r4 = *(const h4*)((const _Float16*)p.resid + (int64_t)m * p.ldr + n);
                                            v[0] = (float)r4[0] + v[0]; v[1] = (float)r4[1] + v[1]; v[2] = (float)r4[2] + v[2]; v[3] = (float)r4[3] + v[3]; }
                         else v = rcur[rr] + v;
@@ -266,14 +269,16 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) k_gemm16(Gemm16P p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = acc[i][j] + b4[j];
                 if (p.q_l2 && sect < 2) {
-                    const f32x4 a0 = v[0] * v[0] + v[2] * v[2], a1 = v[1] * v[1] + v[3] * v[3];
-                    f32x4 bsum = a0 + a1;
+                    // sum of squares over the head's 64 columns in the SAME order as the staged 256x256 epilogue above (there lane c = 4j + kq of a
+                    // 16-lane group holds columns 16j + 4kq .. +3 and runs an xor butterfly 8, 4, 2, 1): four consecutive columns first, then j ^ 2,
+                    // j ^ 1, kq ^ 2, kq ^ 1 — so q and the cached k come out bit-identical whichever tile a launch picks (batch-size invariance)
+                    float sj[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) bsum[e] = bsum[e] + __shfl_xor(bsum[e], 32, 64);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) bsum[e] = bsum[e] + __shfl_xor(bsum[e], 16, 64);
-                    const float t0 = bsum[0] + bsum[2], t1 = bsum[1] + bsum[3];
-                    const float rn = (sect == 0 ? sm : 1.0f) / vm_max(vm_sqrt(t0 + t1), 1e-12f);
+                    for (int j = 0; j < 4; ++j) sj[j] = (v[j][0] * v[j][0] + v[j][1] * v[j][1]) + (v[j][2] * v[j][2] + v[j][3] * v[j][3]);
+                    float w = (sj[0] + sj[2]) + (sj[1] + sj[3]);
+                    w = w + __shfl_xor(w, 32, 64);
+                    w = w + __shfl_xor(w, 16, 64);
+                    const float rn = (sect == 0 ? sm : 1.0f) / vm_max(vm_sqrt(w), 1e-12f);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = v[j] * rn;
                 } else if (!p.q_l2 && sect == 0) {
@@ -289,8 +294,9 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) k_gemm16(Gemm16P p) {
                     if (m >= p.M) continue;
                     const f32x4 w = *(const f32x4*)(stg + rr * SROWW + col * 16);
                     _Float16* dst;
-                    if (sect == 0) dst = p.q_out + (int64_t)m * C + head * 64;
-                    else { const int bb = m / p.q_l, t = m - bb * p.q_l; dst = (sect == 1 ? p.q_kc : p.q_vc) + (((int64_t)bb * Hh + head) * p.q_Lmax + p.q_pos0 + t) * 64; }
+                    const int ma = p.m_base + m;
+                    if (sect == 0) dst = p.q_out + (int64_t)ma * C + head * 64;
+                    else { const int bb = ma / p.q_l, t = ma - bb * p.q_l; dst = (sect == 1 ? p.q_kc : p.q_vc) + (((int64_t)bb * Hh + head) * p.q_Lmax + p.q_pos0 + t) * 64; }
                     h4 o; o[0] = (_Float16)w[0]; o[1] = (_Float16)w[1]; o[2] = (_Float16)w[2]; o[3] = (_Float16)w[3];
                     *(h4*)(dst + col * 4) = o;
                 }
@@ -335,7 +341,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) k_gemm16(Gemm16P p) {
             if (m >= p.M || !n_ok) continue;
             f32x4 v = *(const f32x4*)(stg + rr * SROWW + col * 16);
             if (p.epi == VARHIP_EPI_RESID) {
-                if (p.gamma) v = v * *(const f32x4*)(p.gamma + (int64_t)(m / p.rows_per_group) * p.ldg + n);
+                if (p.gamma) v = v * *(const f32x4*)(p.gamma + (int64_t)((p.m_base + m) / p.rows_per_group) * p.ldg + n);
                 if (p.resid_f16) { const h4 r4 = *(const h4*)((const _Float16*)p.resid + (int64_t)m * p.ldr + n);
                                    v[0] = (float)r4[0] + v[0]; v[1] = (float)r4[1] + v[1]; v[2] = (float)r4[2] + v[2]; v[3] = (float)r4[3] + v[3]; }
                 else if constexpr (PRE) v = rpre[i * NIT + k] + v;
@@ -376,6 +382,49 @@ static int pick_tile16(int M, int N, int batch, bool resid32 = false) {
     return nb128 >= 512 ? 0 : 1;
 }
 
+// A launch of the 256x256 kernel takes ceil(tiles / 256) rounds of (K loop + epilogue) whatever the last round's occupancy (one workgroup
+// per CU): 340 tiles cost two full rounds.  When the last round would be less than 70 % full, the GEMM is issued as TWO launches over row
+// ranges: the rows that fill whole rounds of 256x256 tiles, then the remaining rows with the smaller tiles (two workgroups per CU, short
+// rounds).  Every output element is computed by the same MFMA sequence in either kernel (tests: every tile bit-identical), so the split is
+// invisible in the results.  Returns the number of leading rows for the 256x256 kernel (0: no split, use pick_tile16).
+static int split_rows16(int M, int N, int batch) {
+    if (g_force_tile16 >= 0 || batch != 1) return 0;
+    static const int off = [] { const char* e = getenv("VARHIP_GEMM16_NOSPLIT"); return e ? atoi(e) : 0; }();       // experiments only
+    if (off) return 0;
+    const int tilesN = (N + 255) / 256, tilesM = (M + 255) / 256;
+    const int64_t T = (int64_t)tilesM * tilesN;
+    const int64_t rounds = T / 256;
+    const double frac = (double)T / 256.0 - (double)rounds;
+    if (rounds < 1 || frac == 0.0 || frac >= 0.7) return 0;
+    const int mA = (int)((rounds * 256) / tilesN);                    // m-tiles whose tiles fill `rounds` rounds (252 of 256 slots when tilesN = 12)
+    if (mA < 1 || mA >= tilesM) return 0;
+    return mA * 256;
+}
+
+template <typename F>
+static int run_gemm16(Gemm16P& p, int batch, hipStream_t stream, bool qkv, bool resid32, double bytes_per_row, double bytes_fixed, F&& small_launch) {
+    // one launch, or two over row ranges (split_rows16); every launch is timed in the family of ITS kernel
+    const int M = p.M;
+    const int mA = split_rows16(M, p.N, batch);
+    const char* A0 = (const char*)p.A; char* O0 = (char*)p.out; const char* R0 = (const char*)p.resid;
+    int rc = 0;
+    for (int part = 0; part < (mA ? 2 : 1) && !rc; ++part) {
+        const int m0 = part ? mA : 0, rows = mA ? (part ? M - mA : mA) : M;
+        p.m_base = m0; p.M = rows;
+        p.A = (const _Float16*)(A0 + (int64_t)m0 * p.lda * 2);
+        if (!qkv) {
+            p.out = O0 + (int64_t)m0 * p.ldo * (p.out_f16 ? 2 : 4);
+            p.resid = R0 ? R0 + (int64_t)m0 * p.ldr * (p.resid_f16 ? 2 : 4) : nullptr;
+        }
+        const int pick = (mA && !part) ? 2 : ((mA && part) ? ((int64_t)((rows + 127) / 128) * ((p.N + 127) / 128) >= 384 ? 0 : 1) : pick_tile16(rows, p.N, batch, resid32));
+        VhScope scope(pick == 2 ? VH_FAM_GEMM16 : VH_FAM_GEMM16_SMALL, stream, 2.0 * rows * p.N * (double)p.K * batch,
+                      batch * (rows * bytes_per_row + (part ? 0.0 : bytes_fixed)));
+        rc = pick == 2 ? launch16<8, 4, 2, 4>(p, batch, stream) : small_launch(p, pick, batch, stream);
+    }
+    p.M = M; p.m_base = 0; p.A = (const _Float16*)A0; p.out = O0; p.resid = R0;
+    return rc;
+}
+
 extern "C" int varhip_gemm_nt_f16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                                   void* out, int64_t ldo, int out_f16, int M, int N, int K, int epi,
                                   const void* resid, int64_t ldr, int resid_f16, const float* gamma, int64_t ldg, int rows_per_group,
@@ -391,11 +440,9 @@ extern "C" int varhip_gemm_nt_f16(const void* A, int64_t lda, const void* W, int
     p.A = (const _Float16*)A; p.W = (const _Float16*)W; p.bias = bias; p.out = out; p.resid = resid; p.gamma = gamma;
     p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.ldr = ldr; p.ldg = ldg; p.sA = sA; p.sW = sW; p.sO = sO;
     p.M = M; p.N = N; p.K = K; p.epi = epi; p.rows_per_group = rows_per_group > 0 ? rows_per_group : 1; p.out_f16 = out_f16; p.resid_f16 = resid_f16;
-    const int pick = pick_tile16(M, N, batch, epi == VARHIP_EPI_RESID && !resid_f16);
-    VhScope scope(pick == 2 ? VH_FAM_GEMM16 : VH_FAM_GEMM16_SMALL, (hipStream_t)stream, 2.0 * M * N * (double)K * batch,
-                  batch * (2.0 * ((double)M * K + (double)N * K) + (out_f16 ? 2.0 : 4.0) * (double)M * N));
-    if (pick == 2) return launch16<8, 4, 2, 4>(p, batch, (hipStream_t)stream);
-    return pick == 0 ? launch16<4, 4>(p, batch, (hipStream_t)stream) : launch16<2, 2>(p, batch, (hipStream_t)stream);
+    return run_gemm16(p, batch, (hipStream_t)stream, false, epi == VARHIP_EPI_RESID && !resid_f16,
+                      2.0 * K + (out_f16 ? 2.0 : 4.0) * N, 2.0 * (double)N * K,
+                      [](Gemm16P& q, int pick, int b, hipStream_t s) { return pick == 0 ? launch16<4, 4>(q, b, s) : launch16<2, 2>(q, b, s); });
 }
 
 // mat_qkv in the 16-bit mode: fp16 x fp16 -> fp32 accumulators -> (+bias, q/k L2 norm, scale) in fp32 -> fp16 q and fp16 KV-cache rows
@@ -411,8 +458,6 @@ extern "C" int varhip_gemm_qkv_f16(const void* A, int64_t lda, const void* W, in
     p.M = M; p.N = 3 * C; p.K = K; p.epi = 3; p.rows_per_group = 1;
     p.q_smul = scale_mul; p.q_out = (_Float16*)q_out; p.q_kc = (_Float16*)kcache; p.q_vc = (_Float16*)vcache; p.q_plain = plain_scale;
     p.q_l2 = l2norm; p.q_l = l; p.q_pos0 = pos0; p.q_Lmax = Lmax;
-    const int pick = pick_tile16(M, 3 * C, 1);
-    VhScope scope(pick == 2 ? VH_FAM_GEMM16 : VH_FAM_GEMM16_SMALL, (hipStream_t)stream, 2.0 * M * 3.0 * C * (double)K, 2.0 * ((double)M * K + 3.0 * C * K + 3.0 * M * C));
-    if (pick == 2) return launch16<8, 4, 2, 4>(p, 1, (hipStream_t)stream);
-    return pick == 0 ? launch16<4, 4>(p, 1, (hipStream_t)stream) : launch16<2, 4>(p, 1, (hipStream_t)stream);
+    return run_gemm16(p, 1, (hipStream_t)stream, true, false, 2.0 * K + 2.0 * 3.0 * C, 2.0 * 3.0 * C * (double)K,
+                      [](Gemm16P& q, int pick, int b, hipStream_t s) { return pick == 0 ? launch16<4, 4>(q, b, s) : launch16<2, 4>(q, b, s); });
 }

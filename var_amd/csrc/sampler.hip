@@ -3,49 +3,85 @@
 // cumsum over every row) and consumes the same Exp(1) noise tensor torch.multinomial would draw.
 //
 // Integer-exact by construction: top-k is a radix select on the monotone integer image of the floats, the top-p cut
-// walks the stable ascending order (bitonic sort of (key,index) pairs, only over the entries that survived top-k)
-// with the fp64 running sum ATen's cumsum uses, and the two softmax denominators use the canonical W256 sum.
+// is the one the walk over the stable ascending order (bitonic sort of (key,index) pairs, only over the entries that survived
+// top-k) with the fp64 running sum ATen's cumsum uses would make — decided by a parallel prefix sum wherever that is provably the
+// same decision, by the walk itself otherwise — and the two softmax denominators use the canonical W256 sum.
 #include "common.h"
 
 __device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int src) {
     return ((unsigned long long)__shfl((unsigned)(v >> 32), src, 64) << 32) | (unsigned)__shfl((unsigned)v, src, 64);
 }
 
+// block-wide inclusive prefix sums over the 256 threads (thread order); `sw` holds 4 slots; contains one barrier
+__device__ __forceinline__ int vs_scan256_i(int v, int* sw) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(v, off, 64); if (lane >= off) v += o; }
+    if (lane == 63) sw[wave] = v;
+    __syncthreads();
+    int add = 0;
+    for (int w = 0; w < wave; ++w) add += sw[w];
+    return v + add;
+}
+__device__ __forceinline__ double vs_scan256_d(double v, double* sw) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const double o = __shfl_up(v, off, 64); if (lane >= off) v += o; }
+    if (lane == 63) sw[wave] = v;
+    __syncthreads();
+    double add = 0.0;
+    for (int w = 0; w < wave; ++w) add += sw[w];
+    return v + add;
+}
+
 __global__ void __launch_bounds__(256) k_cfg_sample(const float* __restrict__ logits, const float* __restrict__ noise, int64_t* __restrict__ idx_out,
                                                     float* __restrict__ masked_out, int64_t rows, int V, float ca, float cb,
-                                                    int top_k, int use_top_p, float thr, int cap) {
+                                                    int top_k, int use_top_p, float thr, int cap, int force_walk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm_raw[];
     float* xs = reinterpret_cast<float*>(sm_raw);                                   // [V] working logits
     unsigned long long* srt = reinterpret_cast<unsigned long long*>(sm_raw + sizeof(float) * V);   // [cap] (key<<32 | idx), cap = pow2 >= top_k (or V)
+    __shared__ int s_hist[2][256];
     __shared__ int s_ci[8];
+    __shared__ double s_cd[4];
     __shared__ float red[4];
     __shared__ unsigned s_cnt;
+    __shared__ int s_sel[2];
+    __shared__ int s_flag;
     __shared__ float s_bv[4]; __shared__ int s_bi[4]; __shared__ int s_bn[4];
 
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t row = blockIdx.x;
     const float* lc = logits + row * V;
     const float* lu = logits + (rows + row) * V;
 
     // (1) CFG combine: (1+t)*cond - t*uncond, three roundings as in the reference's tensor expression
     for (int i = tid; i < V; i += 256) { const float a = ca * lc[i]; const float b = cb * lu[i]; xs[i] = a - b; }
+    s_hist[0][tid] = 0;
     __syncthreads();
 
-    // (2) top-k: the key of the k-th largest, built bit by bit from the top: T is the largest value with count(key >= T) >= k.
-    // 32 exact integer block reductions, no atomics (a radix histogram serialises on the few populated top-byte bins).
-    unsigned T = 0u;                                   // key of the k-th largest (0: no top-k, every key is >= it)
+    // (2) top-k: T = key of the k-th largest, by an 8-bit radix select on the monotone integer image of the floats (four passes: count
+    // the candidates per value of the current byte, walk the 256 counts from the top).  Round 2 built T bit by bit: 32 block reductions.
+    unsigned T = 0u;                                   // (0: no top-k, every key is >= it)
     if (top_k > 0) {
-        for (int bit = 31; bit >= 0; --bit) {
-            const unsigned cand = T | (1u << bit);
-            int cnt = 0;
-            for (int i = tid; i < V; i += 256) cnt += (vm_float_key(xs[i]) >= cand) ? 1 : 0;
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
-            if ((tid & 63) == 0) s_ci[(bit & 1) * 4 + (tid >> 6)] = cnt;      // two alternating slots: one barrier per round
+        unsigned prefix = 0u, mask = 0u;
+        int need = top_k;                              // T is the need-th largest of the keys with (key & mask) == prefix
+#pragma unroll 1
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            int* hist = s_hist[pass & 1];
+            s_hist[(pass + 1) & 1][tid] = 0;           // the other table: next pass (nobody reads it before two barriers from here)
+            for (int i = tid; i < V; i += 256) {
+                const unsigned key = vm_float_key(xs[i]);
+                if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
+            }
             __syncthreads();
-            const int* c4 = s_ci + (bit & 1) * 4;
-            if (c4[0] + c4[1] + c4[2] + c4[3] >= top_k) T = cand;
+            const int mine = hist[255 - tid];          // thread t owns byte value 255 - t: the inclusive scan is the count of candidates >= that value
+            const int incl = vs_scan256_i(mine, s_ci);
+            if (incl >= need && incl - mine < need) { s_sel[0] = 255 - tid; s_sel[1] = incl - mine; }
+            __syncthreads();
+            prefix |= (unsigned)s_sel[0] << shift; mask |= 255u << shift; need -= s_sel[1];
         }
+        T = prefix;
         for (int i = tid; i < V; i += 256) if (vm_float_key(xs[i]) < T) xs[i] = -INFINITY;
         __syncthreads();
     }
@@ -63,38 +99,60 @@ __global__ void __launch_bounds__(256) k_cfg_sample(const float* __restrict__ lo
         const float S = vh_block_sum256(part, red);
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) fin += __shfl_xor(fin, off, 64);
-        if ((tid & 63) == 0) s_ci[tid >> 6] = fin;
-        if (tid == 0) s_cnt = 0u;
+        if (lane == 0) s_ci[4 + wave] = fin;
+        if (tid == 0) { s_cnt = 0u; s_flag = 0; }
         __syncthreads();
-        const int total = s_ci[0] + s_ci[1] + s_ci[2] + s_ci[3];      // survivors of top-k (ties with the k-th value included)
+        const int total = s_ci[4] + s_ci[5] + s_ci[6] + s_ci[7];      // survivors of top-k (ties with the k-th value included)
         // The sort buffer holds `cap` entries (a power of two >= top_k, so that more workgroups fit a CU).  Only a crowd of exact
         // ties with the k-th value can exceed it; those ties are the SMALLEST survivors and sort among themselves by index, so
         // they need no sorting: in that case only the entries strictly above the k-th value (< top_k of them) are sorted and the
         // tie group is walked in index order first.
         const bool split = total > cap;
-        // compact (order irrelevant: they get sorted), pad to a power of two with +max keys
-        for (int i = tid; i < V; i += 256) {
+        // compact (order irrelevant: they get sorted): one counter update per wave and step (ballot), not one per entry
+        for (int i0 = 0; i0 < V; i0 += 256) {
+            const int i = i0 + tid;
             const float v = xs[i];
-            if (v > -INFINITY && (!split || vm_float_key(v) > T)) { const unsigned pos = atomicAdd(&s_cnt, 1u); srt[pos] = ((unsigned long long)vm_float_key(v) << 32) | (unsigned)i; }
+            const bool take = v > -INFINITY && (!split || vm_float_key(v) > T);
+            const unsigned long long bal = __ballot(take);
+            unsigned base = 0u;
+            if (lane == 0 && bal) base = atomicAdd(&s_cnt, (unsigned)__popcll(bal));
+            base = __shfl(base, 0, 64);
+            if (take) srt[base + __popcll(bal & ((1ull << lane) - 1ull))] = ((unsigned long long)vm_float_key(v) << 32) | (unsigned)i;
         }
         __syncthreads();
         const int cnt = (int)s_cnt;
         int n2 = 2; while (n2 < cnt) n2 <<= 1;
-        for (int i = cnt + tid; i < n2; i += 256) srt[i] = ~0ull;
+        for (int i = cnt + tid; i < n2; i += 256) srt[i] = ~0ull;       // pad to a power of two with +max keys
         __syncthreads();
+        // bitonic sort, ascending (key, index).  A wave owns a quarter of the entries: every stage whose partner distance j stays inside a
+        // quarter needs no workgroup barrier (a wave's LDS operations complete in order): 52 of the 55 stages at 1024 entries.
+        const int bs = n2 >= 256 ? (n2 >> 2) : n2;                      // entries per wave block (small sorts: wave 0 alone)
+        const bool active = n2 >= 256 || wave == 0;
         for (int k = 2; k <= n2; k <<= 1) {
             for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int i = tid; i < n2; i += 256) {
-                    const int ixj = i ^ j;
-                    if (ixj > i) {
-                        const unsigned long long a = srt[i], b = srt[ixj];
-                        const bool up = (i & k) == 0;
-                        if ((a > b) == up) { srt[i] = b; srt[ixj] = a; }
+                if (j >= bs) {                                           // partners in different waves' blocks
+                    __syncthreads();
+                    for (int i = tid; i < n2; i += 256) {
+                        const int ixj = i ^ j;
+                        if (ixj > i) {
+                            const unsigned long long a = srt[i], b = srt[ixj];
+                            if ((a > b) == ((i & k) == 0)) { srt[i] = b; srt[ixj] = a; }
+                        }
                     }
+                    __syncthreads();
+                } else if (active) {
+                    for (int i = wave * bs + lane; i < (wave + 1) * bs && i < n2; i += 64) {
+                        const int ixj = i ^ j;
+                        if (ixj > i) {
+                            const unsigned long long a = srt[i], b = srt[ixj];
+                            if ((a > b) == ((i & k) == 0)) { srt[i] = b; srt[ixj] = a; }
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's exchanges have landed before its next stage reads them
                 }
-                __syncthreads();
             }
         }
+        __syncthreads();
         // every sorted survivor's probability replaces the (now useless) key half of its sort entry ...
         for (int sidx = tid; sidx < cnt; sidx += 256) {
             const unsigned i = (unsigned)srt[sidx];
@@ -104,8 +162,36 @@ __global__ void __launch_bounds__(256) k_cfg_sample(const float* __restrict__ lo
         // ... so that the ascending walk with the fp64 running sum (ATen's cumsum order) is a bare add/compare per entry.
         // Masked (-inf) entries precede everything and add exactly 0; the removed set is a prefix of the order (cum is
         // non-decreasing); the last (largest) entry is never removed.
+        //
+        // The walk is sequential by definition (fp64 additions in ascending order, each running sum rounded to fp32 and compared with thr),
+        // but its OUTCOME — how long the removed prefix is — can be decided in parallel: any order of summing non-negative doubles is within
+        // n * 2^-53 (relative) of any other, so a blocked parallel prefix sum C^ is within 1e-12 of the sequential running sum c, and
+        // (float)c <= thr  <=>  c below the midpoint `mid` of thr and the next float (at the midpoint itself: ties-to-even).  Whenever every
+        // C^ is farther than 1e-9 (relative) from mid, the parallel decision IS the sequential one; otherwise (and for a tie crowd beyond the
+        // sort buffer, and for degenerate thresholds) one thread walks as before.
+        bool serial = split || !(thr > 1e-30f) || cnt < 2 || force_walk;
+        if (!serial) {
+            const double mid = 0.5 * ((double)thr + (double)__uint_as_float(__float_as_uint(thr) + 1u));
+            const int g = (cnt + 255) >> 8, s0 = tid * g, s1 = (s0 + g < cnt) ? s0 + g : cnt;
+            double loc = 0.0;
+            for (int sidx = s0; sidx < s1; ++sidx) loc += (double)__uint_as_float((unsigned)(srt[sidx] >> 32));
+            const double base = vs_scan256_d(loc, s_cd) - loc;            // sum of everything before this thread's run
+            double c = base; int nrm = 0, edge = 0;
+            for (int sidx = s0; sidx < s1; ++sidx) {
+                c += (double)__uint_as_float((unsigned)(srt[sidx] >> 32));
+                if (sidx < cnt - 1) {                                      // (the last entry is never removed)
+                    if (fabs(c - mid) <= 1e-9 * mid) edge = 1;
+                    else if (c < mid) ++nrm;
+                }
+            }
+            if (edge) atomicOr(&s_flag, 1);
+            __syncthreads();
+            serial = s_flag != 0;
+            if (!serial)
+                for (int sidx = s0; sidx < s0 + nrm; ++sidx) xs[(unsigned)srt[sidx]] = -INFINITY;     // (c is non-decreasing: this thread's removed entries are a prefix of its run)
+        }
         // (entries are fetched eight at a time so the LDS latency is paid once per batch, not once per add)
-        if (tid == 0) {
+        if (serial && tid == 0) {
             double c = 0.0;
             bool done = false;
             int left = total - 1;                                   // entries that may still be removed
@@ -169,6 +255,10 @@ __global__ void __launch_bounds__(256) k_cfg_sample(const float* __restrict__ lo
     if (masked_out) for (int i = tid; i < V; i += 256) masked_out[row * V + i] = xs[i];
 }
 
+static int g_sampler_force_walk = 0;
+// testing: 1 = decide every top-p cut by the sequential walk (the definition), 0 = by the parallel prefix sum wherever that is provably the same
+extern "C" int varhip_sampler_force_walk(int on) { g_sampler_force_walk = on ? 1 : 0; return 0; }
+
 extern "C" int varhip_cfg_sample_f32(const float* logits, const float* noise, int64_t* idx_out, float* masked_out,
                                      int B, int l, int V, double t_cfg, int top_k, double top_p, varhip_stream_t stream) {
     if (B <= 0 || l <= 0 || V <= 0 || (V & 255) || V > 8192 || top_k < 0 || top_k > V) return VARHIP_EINVAL;
@@ -179,7 +269,7 @@ extern "C" int varhip_cfg_sample_f32(const float* logits, const float* noise, in
     if (!attr_done) { (void)hipFuncSetAttribute((const void*)k_cfg_sample, hipFuncAttributeMaxDynamicSharedMemorySize, 12 * 8192); attr_done = true; }
     VhScope sc(VH_FAM_SAMPLER, (hipStream_t)stream, 0, 4.0 * rows * V * 3.0);
     hipLaunchKernelGGL(k_cfg_sample, dim3((unsigned)rows), dim3(256), lds, (hipStream_t)stream, logits, noise, idx_out, masked_out, rows, V,
-                       (float)(1.0 + t_cfg), (float)t_cfg, top_k, top_p > 0.0 ? 1 : 0, (float)(1.0 - top_p), cap);
+                       (float)(1.0 + t_cfg), (float)t_cfg, top_k, top_p > 0.0 ? 1 : 0, (float)(1.0 - top_p), cap, g_sampler_force_walk);
     return vh_launch_status();
 }
 
