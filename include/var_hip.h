@@ -277,6 +277,9 @@ int varhip_gemm_nt_f16(const void* A, int64_t lda, const void* W, int64_t ldw, c
                        int batch, int64_t sA, int64_t sW, int64_t sO, varhip_stream_t stream);
 /* testing / experiments: force the tile of the following f16 GEMM calls (0: 128x128, 1: 64x64, 2: 256x256 with 8 waves; -1: automatic choice) */
 int varhip_gemm16_force_tile(int tile);
+/* experiments / tests: 1 (default) = whole 256x256 tiles run on the persistent kernel k_gemm16p (one workgroup per CU walking a tile list),
+ * 0 = on k_gemm16<8,4,2,4> (one workgroup per tile).  Identical results. */
+int varhip_gemm16_persistent(int on);
 /* mat_qkv + q/k L2-norm + scale + KV-cache append (basic_var.py:93-109): fp16 x fp16 -> fp32 -> fp16 q [M][C] and fp16 caches [B2][H][Lmax][64] */
 int varhip_gemm_qkv_f16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, int M, int C, int K,
                         const float* scale_mul, float plain_scale, int l2norm,

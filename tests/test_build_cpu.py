@@ -50,7 +50,7 @@ def test_checker_scratch_rules():
             'k2:                 ; @k2', '.LBB1_0:', '\tscratch_store_dword off, v1, off', '.LBB1_1:       ; =>This Inner Loop Header: Depth=1', '\tv_add_f32 v1, v1, v1', '\ts_endpgm',
             '    .name:           k1', '    .private_segment_fixed_size: 8', '    .sgpr_spill_count: 0', '    .vgpr_spill_count: 2',
             '    .name:           k2', '    .private_segment_fixed_size: 4', '    .sgpr_spill_count: 0', '    .vgpr_spill_count: 1',
-            '    .name:           k3', '    .private_segment_fixed_size: 0', '    .sgpr_spill_count: 0', '    .vgpr_spill_count: 0']
+            '    .name:           k3', '    .private_segment_fixed_size: 0', '    .sgpr_spill_count: 39', '    .vgpr_spill_count: 0']      # SGPRs in VGPR lanes: no memory
     assert len(cka.check_scratch(meta)) == 2
     assert len(cka.check_scratch(meta, outside_ok=['k2'])) == 1                        # k2 spills outside its loop only
     bad = cka.check_scratch(meta, outside_ok=['k1', 'k2'])

@@ -120,6 +120,35 @@ def test_gemm16_at_d30_d36_widths_every_tile(tile, N, K, mode):
     assert bool((err <= tol).all()), f'{mode} {M}x{N}x{K} tile {tile}: {int((err > tol).sum())} outside tolerance, max err {float(err.max()):.3e}'
 
 
+@pytest.mark.parametrize('M,N,K,mode', [(256, 256, 64, 'none16'), (2048, 768, 192, 'gelu16'), (8192, 3072, 1024, 'none16'), (4096, 1024, 1024, 'resid32'),
+                                        (12800, 1024, 4096, 'resid32'), (33024, 512, 64, 'none32'), (4352, 4096, 128, 'gelu16')])
+def test_gemm16_persistent_kernel_equals_one_tile_kernel(M, N, K, mode):
+    """whole 256x256 tiles on the persistent kernel (k_gemm16p: one workgroup per CU walks a tile list, the next tile's first K tile requested
+    during the last K step, stores left in flight) against the same tiles on k_gemm16<8,4,2,4>: identical bits; 1 to 6 tiles per workgroup,
+    K of one tile step (the prefetch is issued in the only step) to 64, every epilogue; and right against float64 on a sample of rows"""
+    hip = _hip()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = (torch.randn(M, K, generator=g) * 0.7).half().cuda(); W = (torch.randn(N, K, generator=g) * (1.5 / K ** 0.5)).half().cuda()
+    bias = (torch.randn(N, generator=g) * 0.2).cuda(); resid = torch.randn(M, N, generator=g).cuda(); gamma = (torch.randn((M + 99) // 100, N, generator=g) * 0.5).cuda()
+    out16 = mode in ('none16', 'gelu16'); epi = {'none16': 0, 'none32': 0, 'gelu16': 1, 'resid32': 2}[mode]
+    def run(persist, tile):
+        out = torch.empty(M, N, dtype=torch.float16 if out16 else torch.float32, device='cuda')
+        hip.lib().so.varhip_gemm16_persistent(persist); hip.lib().so.varhip_gemm16_force_tile(tile)
+        try: hip.call('gemm_nt_f16', A, K, W, K, bias, out, N, int(out16), M, N, K, epi, resid if epi == 2 else None, N, 0, gamma if epi == 2 else None, N, 100, 1, 0, 0, 0)
+        finally: hip.lib().so.varhip_gemm16_persistent(1); hip.lib().so.varhip_gemm16_force_tile(-1)
+        return out
+    a, b, c = run(1, 2), run(0, 2), run(1, 1)
+    assert torch.equal(a, b), f'persistent vs one-tile kernel: {int((a != b).sum())} elements differ'
+    assert torch.equal(a, c), f'persistent 256x256 vs 64x64 tiles: {int((a != c).sum())} elements differ'
+    assert torch.equal(run(1, 2), a)                                      # run to run
+    rows = torch.randperm(M, generator=g)[:64]
+    ref = A[rows].double().cpu() @ W.double().cpu().T + bias.double().cpu()
+    if epi == 1: ref = torch.nn.functional.gelu(ref, approximate='tanh')
+    if epi == 2: ref = resid[rows].double().cpu() + ref * gamma.double().cpu()[(rows // 100)]
+    err = (a[rows].double().cpu() - ref).abs()
+    assert float(err.max()) <= 2e-3 + (float(ref.abs().max()) * 2.0 ** -10 if out16 else 0.0), f'max err {float(err.max()):.3e}'
+
+
 def test_gemm16_row_split_launches_are_invisible():
     """a GEMM whose last round of 256x256 tiles would be under 70 % full goes out as two launches over row ranges (the rows that fill whole
     rounds on the 256x256 kernel, the rest on a small-tile kernel): same bits as a single-kernel run, right against float64; the row offset

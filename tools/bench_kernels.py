@@ -174,6 +174,24 @@ def run_attn16(iters):
         print(f'attn16 l={l:3d} curL={cur:3d}: {ms*1e3:9.1f} us  {tf:6.1f} TF (algorithmic)', flush=True)
 
 
+def run_sampler(iters):
+    """CFG + top-k 900 + top-p 0.96 + multinomial (varhip_cfg_sample_f32) at the d16 / B=64 shapes; bytes = two logits rows + one noise row per token"""
+    dev, B, V = 'cuda', 64, 4096
+    tot_ms, tot_b = 0.0, 0.0
+    for pn in (1, 2, 3, 4, 5, 6, 8, 10, 13, 16):
+        l = pn * pn
+        logits = torch.randn(2 * B * l, V, device=dev) * 2.0; noise = torch.empty(B * l, V, device=dev).exponential_(1)
+        idx = torch.empty(B * l, dtype=torch.int64, device=dev)
+        for walk in (0, 1):
+            hip.lib().so.varhip_sampler_force_walk(walk)
+            fn = lambda: hip.call('cfg_sample_f32', logits, noise, idx, None, B, l, V, 0.75, 900, 0.96)
+            ms = timeit(fn, iters)
+            if walk == 0: tot_ms += ms; tot_b += 12.0 * B * l * V
+            print(f'sampler l={l:3d} rows={B * l:6d} {"walk    " if walk else "parallel"}: {ms * 1e3:9.1f} us  {12.0 * B * l * V / ms / 1e6:8.1f} GB/s', flush=True)
+        hip.lib().so.varhip_sampler_force_walk(0)
+    print(f'sampler total (parallel cut) {tot_ms:.3f} ms per step, {tot_b / tot_ms / 1e6:.1f} GB/s of 8000', flush=True)
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('what', nargs='?', default='all')
@@ -188,3 +206,4 @@ if __name__ == '__main__':
     if a.what == 'conv16': run_conv16(a.iters)
     if a.what in ('gemm16', 'all16'): run_gemm16(a.iters)
     if a.what in ('attn16', 'all16'): run_attn16(a.iters)
+    if a.what in ('sampler', 'all'): run_sampler(a.iters)

@@ -355,6 +355,203 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) k_gemm16(Gemm16P p) {
     }
 }
 
+// ---- k_gemm16p: the 256x256 tile as a PERSISTENT workgroup ---------------------------------------------------------------------------
+// One workgroup of 8 waves per CU walks a list of tiles instead of exiting after one.  What that buys (12-30 us per tile sit
+// outside the K loop of k_gemm16<8,4,2,4>, a third to 60 % of a K = 1024 tile):
+//   * the next tile's first K tile is requested at the middle of the current tile's LAST K step and lands while the epilogue runs: no
+//     workgroup launch, no cold first request, no pipeline fill between tiles;
+//   * the epilogue's stores are not waited for: the K loop of the next tile starts while they drain (the first wait of the next tile is a
+//     counted vmcnt that covers the prefetched tile only);
+//   * tiles are dealt so that the 32 workgroups of an XCD always work on 32 consecutive tiles of that XCD's contiguous share of the tile
+//     list (8 m-tiles x 4 n-tiles: the panels its 4 MB L2 holds), as the one-tile kernel's dispatch order did.
+// LDS (all 160 KB): [stage 0: 64 KB][spare: 32 KB][stage 1: 64 KB].  The epilogue parks in the stage the last K step was read from plus the
+// spare (96 KB contiguous, either way round) while the other stage receives the next tile.  Arithmetic, fragment reads, epilogue math:
+// k_gemm16<8,4,2,4>'s, statement for statement — the results are bit-identical (tests: every tile on ragged shapes).
+#define G16P_STAGE 65536
+#define G16P_SPARE 32768
+__global__ void __launch_bounds__(512, 2) k_gemm16p(Gemm16P p) {
+    constexpr int TMW = 8, TNW = 4, WM = 2, WN = 4, NWAVE = 8, BM = 256, BN = 256, ROWB = 128;
+    constexpr int NIA = BM / NWAVE / 8, NIB = BN / NWAVE / 8;
+    extern __shared__ __attribute__((aligned(16))) char smem16[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int drow = lane >> 3, dslot = lane & 7, r16 = lane & 15, kq = lane >> 4;
+    const int nk = p.K / 64, bz = blockIdx.z;
+    const char* Ab = (const char*)(p.A + (int64_t)bz * p.sA);
+    const char* Wb = (const char*)(p.W + (int64_t)bz * p.sW);
+    // this workgroup's tiles: XCD x = bid & 7 owns the contiguous share [start, start + share) of the tile list (as k_gemm16's block order);
+    // its workgroup number `loc` (0 .. per_xcd - 1) takes the tiles start + loc, start + loc + per_xcd, ...
+    const int nwg = p.tilesM * p.tilesN, bid = blockIdx.x, per_xcd = gridDim.x >> 3;
+    const int xq = nwg >> 3, xrem = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    const int share = xq + (xcd < xrem ? 1 : 0), start = xcd < xrem ? xcd * (xq + 1) : xrem * (xq + 1) + (xcd - xrem) * xq;
+    if (loc >= share) return;
+    auto tile_of = [&](int lin, int& m0, int& n0) {
+        const int GM = 8, width = GM * p.tilesN, group = lin / width, first = group * GM;
+        const int gsz = (p.tilesM - first) < GM ? (p.tilesM - first) : GM;
+        m0 = (first + (lin % width) % gsz) * BM; n0 = ((lin % width) / gsz) * BN;
+    };
+    auto offsets = [&](int m0, int n0, uint32_t* aoff, uint32_t* boff) {
+#pragma unroll
+        for (int i = 0; i < NIA; ++i) { int m = m0 + wave * (BM / NWAVE) + i * 8 + drow; m = m < p.M ? m : p.M - 1; aoff[i] = (uint32_t)((int64_t)m * p.lda * 2 + ((dslot ^ drow) << 4)); }
+#pragma unroll
+        for (int i = 0; i < NIB; ++i) { int n = n0 + wave * (BN / NWAVE) + i * 8 + drow; n = n < p.N ? n : p.N - 1; boff[i] = (uint32_t)((int64_t)n * p.ldw * 2 + ((dslot ^ drow) << 4)); }
+    };
+    auto stage_base = [&](int st) -> char* { return smem16 + (st ? G16P_STAGE + G16P_SPARE : 0); };
+    auto dma_tile = [&](int kt, int st, const uint32_t* aoff, const uint32_t* boff) {
+        char* sA = stage_base(st) + wave * (BM / NWAVE) * ROWB;
+        char* sB = stage_base(st) + BM * ROWB + wave * (BN / NWAVE) * ROWB;
+#pragma unroll
+        for (int i = 0; i < NIA; ++i)
+            vh16_dma16(Ab + (size_t)kt * ROWB, aoff[i], (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(sA + i * 8 * ROWB));
+#pragma unroll
+        for (int i = 0; i < NIB; ++i)
+            vh16_dma16(Wb + (size_t)kt * ROWB, boff[i], (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(sB + i * 8 * ROWB));
+    };
+
+    int lin = start + loc, m0, n0;
+    tile_of(lin, m0, n0);
+    uint32_t aoff[NIA], boff[NIB], naoff[NIA], nboff[NIB];
+    offsets(m0, n0, aoff, boff);
+    dma_tile(0, 0, aoff, boff);
+    int st = 0;                                        // stage of the K tile about to be multiplied
+#pragma unroll 1
+    for (int idx = loc; idx < share; idx += per_xcd) {
+        const bool has_next = idx + per_xcd < share;
+        int nm0 = 0, nn0 = 0;
+        if (has_next) tile_of(lin + per_xcd, nm0, nn0);
+        // the prefetched first K tile of this tile has landed: it is older than every store of the previous epilogue (32 per wave when that
+        // was the full-tile epilogue: a counted wait leaves them in flight; otherwise drain)
+        if (idx != loc) vh16_waitcnt_barrier<32>(); else vh16_waitcnt_barrier<0>();
+        f32x4 acc[TMW][TNW];
+#pragma unroll
+        for (int i = 0; i < TMW; ++i)
+#pragma unroll
+            for (int j = 0; j < TNW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int kt = 0; kt < nk; ++kt) {
+            const bool last = kt + 1 == nk;
+            if (last && has_next) offsets(nm0, nn0, naoff, nboff);
+            auto mid = [&] { if (!last) dma_tile(kt + 1, st ^ 1, aoff, boff); else if (has_next) dma_tile(0, st ^ 1, naoff, nboff); };
+            {
+                const char* sA = stage_base(st) + (wm * TMW * 16 + r16) * ROWB;
+                const char* sB = stage_base(st) + BM * ROWB + (wn * TNW * 16 + r16) * ROWB;
+                h8 bn[2][TNW], am[TMW];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int sl = ((4 * s2 + kq) ^ (r16 & 7)) << 4;
+#pragma unroll
+                    for (int j = 0; j < TNW; ++j) bn[s2][j] = *(const h8*)(sB + j * 16 * ROWB + sl);
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int sl = ((4 * s2 + kq) ^ (r16 & 7)) << 4;
+#pragma unroll
+                    for (int i = 0; i < TMW; ++i) am[i] = *(const h8*)(sA + i * 16 * ROWB + sl);
+#pragma unroll
+                    for (int i = 0; i < TMW; ++i)
+#pragma unroll
+                        for (int j = 0; j < TNW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bn[s2][j], am[i], acc[i][j], 0, 0, 0);
+                    if (s2 == 0) mid();
+                }
+            }
+            // every wave is done reading stage st; except behind the last K step (the epilogue comes first) the next K tile must have landed
+            if (!last) vh16_waitcnt_barrier<0>(); else asm volatile("s_barrier" ::: "memory");
+            st ^= 1;
+        }
+        // ---- epilogue of tile (m0, n0): parks in the stage just read (st ^ 1) + the spare; stage st holds / receives the next tile
+        char* const parkbase = smem16 + ((st ^ 1) ? G16P_STAGE : 0);
+        {   // (full tiles only: the host sends M % 256 rows and GEMMs with N % 256 != 0 to the one-tile kernels)
+            constexpr int SROW = BN * 4 + 64;
+            static_assert(2 * 32 * SROW <= G16P_STAGE + G16P_SPARE, "two parking areas");
+            const int n = n0 + lane * 4;
+            const f32x4 b4 = p.bias ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            int sect = 0, head = 0, Cq = 0, Hh = 0; float sm = 1.0f;
+            if (p.epi == 3) { Cq = p.N / 3; sect = n / Cq; head = (n - sect * Cq) >> 6; Hh = Cq >> 6;
+                              sm = (p.q_l2 && sect == 0) ? vm_exp(vm_min(p.q_smul[head], 4.605170249938965f)) : 1.0f; }
+            char* Ob = (char*)p.out + (int64_t)bz * p.sO * (p.out_f16 ? 2 : 4);
+            const bool res32 = p.epi == VARHIP_EPI_RESID && !p.resid_f16;
+            f32x4 rcur[4], rnxt[4];
+            auto res_rows = [&](int i, f32x4* r) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) { const int sr = 4 * wave + rr, m = m0 + (sr >> 4) * (TMW * 16) + i * 16 + (sr & 15);
+                                                 r[rr] = *(const f32x4*)((const float*)p.resid + (int64_t)m * p.ldr + n); }
+            };
+            if (res32) res_rows(0, rcur);
+#pragma unroll
+            for (int i = 0; i < TMW; ++i) {
+                char* const park = parkbase + (i & 1) * 32 * SROW;
+                char* wr = park + (wm * 16 + r16) * SROW + (wn * 64 + kq * 4) * 4;
+#pragma unroll
+                for (int j = 0; j < TNW; ++j) *(f32x4*)(wr + j * 64) = acc[i][j];
+                if (res32 && i + 1 < TMW) res_rows(i + 1, rnxt);
+                __syncthreads();
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int sr = 4 * wave + rr, m = m0 + (sr >> 4) * (TMW * 16) + i * 16 + (sr & 15);
+                    f32x4 v = *(const f32x4*)(park + sr * SROW + lane * 16) + b4;
+                    if (p.epi == 3) {
+                        if (p.q_l2 && sect < 2) {
+                            float ss = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+#pragma unroll
+                            for (int off = 8; off >= 1; off >>= 1) ss = ss + __shfl_xor(ss, off, 64);
+                            v = v * ((sect == 0 ? sm : 1.0f) / vm_max(vm_sqrt(ss), 1e-12f));
+                        } else if (!p.q_l2 && sect == 0) v = v * p.q_plain;
+                        _Float16* dst;
+                        const int ma = p.m_base + m;
+                        if (sect == 0) dst = p.q_out + (int64_t)ma * Cq + head * 64;
+                        else { const int bb = ma / p.q_l, t = ma - bb * p.q_l; dst = (sect == 1 ? p.q_kc : p.q_vc) + (((int64_t)bb * Hh + head) * p.q_Lmax + p.q_pos0 + t) * 64; }
+                        h4 o; o[0] = (_Float16)v[0]; o[1] = (_Float16)v[1]; o[2] = (_Float16)v[2]; o[3] = (_Float16)v[3];
+                        *(h4*)(dst + (lane & 15) * 4) = o;
+                        continue;
+                    }
+                    if (p.epi == VARHIP_EPI_GELU) { v[0] = vh16_gelu(v[0]); v[1] = vh16_gelu(v[1]); v[2] = vh16_gelu(v[2]); v[3] = vh16_gelu(v[3]); }
+                    else if (p.epi == VARHIP_EPI_RESID) {
+                        if (p.gamma) v = v * *(const f32x4*)(p.gamma + (int64_t)((p.m_base + m) / p.rows_per_group) * p.ldg + n);
+                        if (p.resid_f16) { const h4 r4 = *(const h4*)((const _Float16*)p.resid + (int64_t)m * p.ldr + n);
+                                           v[0] = (float)r4[0] + v[0]; v[1] = (float)r4[1] + v[1]; v[2] = (float)r4[2] + v[2]; v[3] = (float)r4[3] + v[3]; }
+                        else v = rcur[rr] + v;
+                    }
+                    if (p.out_f16) { h4 o; o[0] = (_Float16)v[0]; o[1] = (_Float16)v[1]; o[2] = (_Float16)v[2]; o[3] = (_Float16)v[3];
+                                     *(h4*)(Ob + ((int64_t)m * p.ldo + n) * 2) = o; }
+                    else *(f32x4*)(Ob + ((int64_t)m * p.ldo + n) * 4) = v;
+                }
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) rcur[rr] = rnxt[rr];
+            }
+        }
+        if (has_next) {
+            lin += per_xcd; m0 = nm0; n0 = nn0;
+#pragma unroll
+            for (int i = 0; i < NIA; ++i) aoff[i] = naoff[i];
+#pragma unroll
+            for (int i = 0; i < NIB; ++i) boff[i] = nboff[i];
+        }
+    }
+}
+
+static int g_gemm16_persist = 1;
+// experiments / A-B: 0 = the 256x256 tile as one workgroup per tile (k_gemm16<8,4,2,4>), 1 (default) = as a persistent workgroup per CU (k_gemm16p)
+extern "C" int varhip_gemm16_persistent(int on) { g_gemm16_persist = on ? 1 : 0; return 0; }
+
+static int launch16p(Gemm16P& p, int batch, hipStream_t stream) {
+    constexpr size_t lds = 2 * (size_t)G16P_STAGE + G16P_SPARE;
+    p.tilesM = (p.M + 255) / 256; p.tilesN = (p.N + 255) / 256;
+    static int ncu = 0;
+    static bool attr_done = false;
+    if (!attr_done) {
+        int dev = 0; (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 8) ncu = 256;
+        (void)hipFuncSetAttribute((const void*)k_gemm16p, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    const int T = p.tilesM * p.tilesN;
+    int per_xcd = ncu / 8 / batch; if (per_xcd < 1) per_xcd = 1;     // workgroups per XCD (batched launches share the CUs over blockIdx.z)
+    const int need = (T + 7) / 8;                                      // the largest XCD share
+    if (per_xcd > need) per_xcd = need;
+    hipLaunchKernelGGL(k_gemm16p, dim3(per_xcd * 8, 1, batch), dim3(512), lds, stream, p);
+    return vh_launch_status();
+}
+
 template <int TMW, int TNW, int WM = 2, int WN = 2>
 static int launch16(Gemm16P& p, int batch, hipStream_t stream) {
     constexpr int BM = TMW * 16 * WM, BN = TNW * 16 * WN;
@@ -403,23 +600,36 @@ static int split_rows16(int M, int N, int batch) {
 
 template <typename F>
 static int run_gemm16(Gemm16P& p, int batch, hipStream_t stream, bool qkv, bool resid32, double bytes_per_row, double bytes_fixed, F&& small_launch) {
-    // one launch, or two over row ranges (split_rows16); every launch is timed in the family of ITS kernel
+    // one launch, or two over row ranges: (a) split_rows16, (b) the persistent 256x256 kernel takes whole tiles only — the last M % 256 rows
+    // go to a small-tile launch.  Every launch is timed in the family of ITS kernel.
     const int M = p.M;
+    const bool persist_ok = g_gemm16_persist && (p.N % 256) == 0;
+    struct Seg { int m0, rows, pick; } seg[2];
+    int nseg = 1;
+    auto small_pick = [&](int rows) { return (int64_t)((rows + 127) / 128) * ((p.N + 127) / 128) >= 384 ? 0 : 1; };
     const int mA = split_rows16(M, p.N, batch);
+    if (mA) { seg[0] = {0, mA, 2}; seg[1] = {mA, M - mA, small_pick(M - mA)}; nseg = 2; }
+    else {
+        const int pick = pick_tile16(M, p.N, batch, resid32);
+        seg[0] = {0, M, pick};
+        if (pick == 2 && persist_ok && g_force_tile16 < 0 && batch == 1 && (M % 256) != 0 && M > 256) {
+            seg[0] = {0, M - M % 256, 2}; seg[1] = {M - M % 256, M % 256, small_pick(M % 256)}; nseg = 2;
+        }
+    }
     const char* A0 = (const char*)p.A; char* O0 = (char*)p.out; const char* R0 = (const char*)p.resid;
     int rc = 0;
-    for (int part = 0; part < (mA ? 2 : 1) && !rc; ++part) {
-        const int m0 = part ? mA : 0, rows = mA ? (part ? M - mA : mA) : M;
+    for (int i = 0; i < nseg && !rc; ++i) {
+        const int m0 = seg[i].m0, rows = seg[i].rows, pick = seg[i].pick;
         p.m_base = m0; p.M = rows;
         p.A = (const _Float16*)(A0 + (int64_t)m0 * p.lda * 2);
         if (!qkv) {
             p.out = O0 + (int64_t)m0 * p.ldo * (p.out_f16 ? 2 : 4);
             p.resid = R0 ? R0 + (int64_t)m0 * p.ldr * (p.resid_f16 ? 2 : 4) : nullptr;
         }
-        const int pick = (mA && !part) ? 2 : ((mA && part) ? ((int64_t)((rows + 127) / 128) * ((p.N + 127) / 128) >= 384 ? 0 : 1) : pick_tile16(rows, p.N, batch, resid32));
         VhScope scope(pick == 2 ? VH_FAM_GEMM16 : VH_FAM_GEMM16_SMALL, stream, 2.0 * rows * p.N * (double)p.K * batch,
-                      batch * (rows * bytes_per_row + (part ? 0.0 : bytes_fixed)));
-        rc = pick == 2 ? launch16<8, 4, 2, 4>(p, batch, stream) : small_launch(p, pick, batch, stream);
+                      batch * (rows * bytes_per_row + (i ? 0.0 : bytes_fixed)));
+        if (pick == 2) rc = (persist_ok && (rows % 256) == 0) ? launch16p(p, batch, stream) : launch16<8, 4, 2, 4>(p, batch, stream);
+        else rc = small_launch(p, pick, batch, stream);
     }
     p.M = M; p.m_base = 0; p.A = (const _Float16*)A0; p.out = O0; p.resid = R0;
     return rc;

@@ -27,6 +27,7 @@ class _Lib:
         so.varhip_timing_name.argtypes = [ctypes.c_int]; so.varhip_timing_name.restype = ctypes.c_char_p
         so.varhip_gemm16_force_tile.argtypes = [ctypes.c_int]; so.varhip_gemm16_force_tile.restype = ctypes.c_int
         so.varhip_conv16_force_tile.argtypes = [ctypes.c_int]; so.varhip_conv16_force_tile.restype = ctypes.c_int
+        so.varhip_gemm16_persistent.argtypes = [ctypes.c_int]; so.varhip_gemm16_persistent.restype = ctypes.c_int
         so.varhip_sampler_force_walk.argtypes = [ctypes.c_int]; so.varhip_sampler_force_walk.restype = ctypes.c_int
 
     def version(self) -> str:
