@@ -155,9 +155,9 @@ def test_gemm16_row_split_launches_are_invisible():
     reaches gamma's row groups (rows_per_group = 300 straddles the cut) and the q/k/v epilogue's (image, position) decode (l = 100)"""
     hip = _hip()
     g = torch.Generator().manual_seed(11)
-    M, N, K = 38400, 512, 64                       # 150 x 2 = 300 tiles: one full round (32768 rows) + 5632 rows
+    M, N, K = 103936, 512, 64                      # 406 x 2 = 812 tiles: three full rounds (98304 rows) + 5632 rows
     A = (torch.randn(M, K, generator=g) * 0.7).half().cuda(); W = (torch.randn(N, K, generator=g) * 0.2).half().cuda()
-    bias = (torch.randn(N, generator=g) * 0.2).cuda(); resid = torch.randn(M, N, generator=g).cuda(); gamma = (torch.randn(128, N, generator=g) * 0.5).cuda()
+    bias = (torch.randn(N, generator=g) * 0.2).cuda(); resid = torch.randn(M, N, generator=g).cuda(); gamma = (torch.randn(347, N, generator=g) * 0.5).cuda()
     def run(t, epi, out16):
         out = torch.empty(M, N, dtype=torch.float16 if out16 else torch.float32, device='cuda')
         hip.lib().so.varhip_gemm16_force_tile(t)
@@ -169,12 +169,12 @@ def test_gemm16_row_split_launches_are_invisible():
     hip.timing_enable(False)
     t = hip.timing_read()
     assert t['gemm16']['launches'] == 1 and t['gemm16_small']['launches'] == 1, 'expected one 256x256 launch + one small-tile launch'
-    assert t['gemm16']['flops'] == 2.0 * 32768 * N * K and t['gemm16_small']['flops'] == 2.0 * 5632 * N * K
+    assert t['gemm16']['flops'] == 2.0 * 98304 * N * K and t['gemm16_small']['flops'] == 2.0 * 5632 * N * K
     assert torch.equal(auto_res, run(1, 2, False)) and torch.equal(run(-1, 1, True), run(1, 1, True))
     ref = resid.double().cpu() + (A.double().cpu() @ W.double().cpu().T + bias.double().cpu()) * gamma.double().cpu().repeat_interleave(300, dim=0)[:M]
     assert float((auto_res.double().cpu() - ref).abs().max()) <= 1e-4
-    # q/k/v: H = 4 heads (N = 768: 3 column tiles), l = 100, B2 = 256 -> 100 x 3 = 300 tiles, the cut at row 21760 falls inside image 217
-    B2, l, H, pos0, Lmax = 256, 100, 4, 7, 120
+    # q/k/v: H = 4 heads (N = 768: 3 column tiles), l = 100, B2 = 700 -> 274 x 3 = 822 tiles, the cut at row 65536 falls inside image 655
+    B2, l, H, pos0, Lmax = 700, 100, 4, 7, 120
     C = H * 64; M2 = B2 * l
     A2 = torch.randn(M2, C, generator=g).half().cuda(); W2 = (torch.randn(3 * C, C, generator=g) * (1.0 / C ** 0.5)).half().cuda()
     b2 = (torch.randn(3 * C, generator=g) * 0.1).cuda(); smul = (torch.randn(H, generator=g) * 0.3 + 1.4).cuda()
@@ -186,7 +186,7 @@ def test_gemm16_row_split_launches_are_invisible():
         finally: hip.lib().so.varhip_gemm16_force_tile(-1)
         outs.append((q, kc, vc))
     for a, b in zip(*outs): assert torch.equal(a, b)
-    assert float(outs[0][1][:, :, :pos0].abs().max()) == 0 and float(outs[0][1][:, :, pos0 + l:].abs().max()) == 0 and float(outs[0][1][217].abs().max()) > 0
+    assert float(outs[0][1][:, :, :pos0].abs().max()) == 0 and float(outs[0][1][:, :, pos0 + l:].abs().max()) == 0 and float(outs[0][1][655].abs().max()) > 0 and float(outs[0][1][699].abs().max()) > 0
 
 
 @pytest.mark.parametrize('B2,l,H,pos0,l2', [(4, 9, 2, 5, 1), (2, 64, 4, 91, 1), (3, 25, 16, 0, 0), (4, 100, 4, 10, 1), (6, 50, 8, 3, 0),

@@ -529,7 +529,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm16p(Gemm16P p) {
     }
 }
 
-static int g_gemm16_persist = 1;
+static int g_gemm16_persist = [] { const char* e = getenv("VARHIP_GEMM16_PERSIST"); return e ? (atoi(e) != 0) : 1; }();
 // experiments / A-B: 0 = the 256x256 tile as one workgroup per tile (k_gemm16<8,4,2,4>), 1 (default) = as a persistent workgroup per CU (k_gemm16p)
 extern "C" int varhip_gemm16_persistent(int on) { g_gemm16_persist = on ? 1 : 0; return 0; }
 
@@ -580,7 +580,7 @@ static int pick_tile16(int M, int N, int batch, bool resid32 = false) {
 }
 
 // A launch of the 256x256 kernel takes ceil(tiles / 256) rounds of (K loop + epilogue) whatever the last round's occupancy (one workgroup
-// per CU): 340 tiles cost two full rounds.  When the last round would be less than 70 % full, the GEMM is issued as TWO launches over row
+// per CU): 1360 tiles cost six full rounds.  When the last round would be less than 70 % full, the GEMM is issued as TWO launches over row
 // ranges: the rows that fill whole rounds of 256x256 tiles, then the remaining rows with the smaller tiles (two workgroups per CU, short
 // rounds).  Every output element is computed by the same MFMA sequence in either kernel (tests: every tile bit-identical), so the split is
 // invisible in the results.  Returns the number of leading rows for the 256x256 kernel (0: no split, use pick_tile16).
@@ -592,7 +592,9 @@ static int split_rows16(int M, int N, int batch) {
     const int64_t T = (int64_t)tilesM * tilesN;
     const int64_t rounds = T / 256;
     const double frac = (double)T / 256.0 - (double)rounds;
-    if (rounds < 1 || frac == 0.0 || frac >= 0.7) return 0;
+    // (measured, tools/bench_kernels.py gemm16 at the d16 shapes: pays from three full rounds on — fc1 at l = 100 / 169: -8 % / -3 %; with one
+    // or two rounds in front the small-tile launch costs what the ragged round did)
+    if (rounds < 3 || frac == 0.0 || frac >= 0.7) return 0;
     const int mA = (int)((rounds * 256) / tilesN);                    // m-tiles whose tiles fill `rounds` rounds (252 of 256 slots when tilesN = 12)
     if (mA < 1 || mA >= tilesM) return 0;
     return mA * 256;
