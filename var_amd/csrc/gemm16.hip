@@ -24,6 +24,7 @@ struct Gemm16P {
     int m_base;                // rows of the GEMM in front of this launch (a GEMM may be issued as two launches over row ranges): A / out / resid are pre-offset, gamma's row
                                // group and the q/k/v epilogue's (image, position) use the absolute row m_base + m
     int tilesM, tilesN;
+    int dbg;                   // experiments (k_gemm16p): bit 0 no global stores, bit 1 no epilogue, bits 8.. stagger (odd workgroups sleep dbg >> 8 x 8k cycles first)
     // epi == 3: fused q/k/v epilogue (N = 3C, head_dim 64)
     const float* q_smul; _Float16* q_out; _Float16* q_kc; _Float16* q_vc; float q_plain; int q_l2, q_l, q_pos0, q_Lmax;
 };
@@ -34,11 +35,28 @@ __device__ __forceinline__ void vh16_dma16(const void* base, uint32_t voff, uint
 }
 
 // GELU (tanh form) for the fp16 output of fc1: x * sigmoid(2u), u = sqrt(2/pi)(x + 0.044715 x^3), with the hardware exp2 / reciprocal
-// (this mode is not bit-compared; the twin uses the same formula with libm: difference ~1e-7 relative, far below the fp16 rounding)
+// (this mode is not bit-compared; the twin uses the same formula with libm: difference ~1e-7 relative, far below the fp16 rounding).
+// exp(-2u) = exp2(x * (c1 + c2 x^2)) with the constants folded: seven instructions per element — the epilogue of the 256x256 tile is bound by
+// vector-instruction issue (measured: it costs 6.6 - 10.7 us of a 26 us tile with the stores taken out)
 __device__ __forceinline__ float vh16_gelu(float x) {
-    const float u = 0.7978845608028654f * (x + 0.044715f * ((x * x) * x));
-    const float e = __builtin_amdgcn_exp2f(u * -2.8853900817779268f);         // exp(-2u)
+    const float t = __builtin_fmaf(x * x, -0.10294323958f, -2.3022081981f);      // -2 log2(e) sqrt(2/pi) * (1 + 0.044715 x^2)
+    const float e = __builtin_amdgcn_exp2f(x * t);                              // exp(-2u)
     return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+// q / k normalisation factor of the fused q/k/v epilogue: scale / max(|v|, 1e-12) as scale * rsq(max(|v|^2, 1e-24)) on the hardware
+// reciprocal square root (1 ulp; the fp16 rounding of q and k is 2^-11) — one instruction where sqrt + IEEE division took ~25
+__device__ __forceinline__ float vh16_qk_rn(float ss, float scale) { return scale * __builtin_amdgcn_rsqf(__builtin_fmaxf(ss, 1e-24f)); }
+
+// sum over the 16 lanes of a row group (every lane ends with the total), partners lane^1, ^2, ^4, ^8 in that order, on DPP moves (the
+// compiler's __shfl_xor goes through ds_bpermute: four dependent LDS round trips per row).  After the first two steps the four lanes of a quad
+// agree, so the half-row mirror (i <-> 7 - i) pairs quads exactly as lane^4 would, and the row mirror (i <-> 15 - i) as lane^8.
+__device__ __forceinline__ float vh16_sum16(float v) {
+    v = v + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
+    v = v + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));     // quad_perm [2,3,0,1]
+    v = v + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true));    // row_half_mirror
+    v = v + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xF, 0xF, true));    // row_mirror
+    return v;
 }
 
 // WM x WN waves, each owning (TMW*16) x (TNW*16) outputs.  2x2 waves: 128x128 / 64x128 / 64x64 tiles, two workgroups per CU.
@@ -210,10 +228,8 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) k_gemm16(Gemm16P p) {
                     f32x4 v = *(const f32x4*)(park + sr * SROW + lane * 16) + b4;
                     if (p.epi == 3) {
                         if (p.q_l2 && sect < 2) {
-                            float ss = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);      // a head = 16 lanes x 4 columns
-#pragma unroll
-                            for (int off = 8; off >= 1; off >>= 1) ss = ss + __shfl_xor(ss, off, 64);
-                            v = v * ((sect == 0 ? sm : 1.0f) / vm_max(vm_sqrt(ss), 1e-12f));
+                            const float ss = vh16_sum16((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));      // a head = 16 lanes x 4 columns
+                            v = v * vh16_qk_rn(ss, sect == 0 ? sm : 1.0f);
                         } else if (!p.q_l2 && sect == 0) v = v * p.q_plain;
                         _Float16* dst;
                         const int ma = p.m_base + m;
@@ -270,15 +286,17 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) k_gemm16(Gemm16P p) {
                 for (int j = 0; j < 4; ++j) v[j] = acc[i][j] + b4[j];
                 if (p.q_l2 && sect < 2) {
                     // sum of squares over the head's 64 columns in the SAME order as the staged 256x256 epilogue above (there lane c = 4j + kq of a
-                    // 16-lane group holds columns 16j + 4kq .. +3 and runs an xor butterfly 8, 4, 2, 1): four consecutive columns first, then j ^ 2,
-                    // j ^ 1, kq ^ 2, kq ^ 1 — so q and the cached k come out bit-identical whichever tile a launch picks (batch-size invariance)
+                    // 16-lane group holds columns 16j + 4kq .. +3 and combines lane ^ 1, ^ 2, ^ 4, ^ 8): four consecutive columns first, then kq ^ 1,
+                    // kq ^ 2, j ^ 1, j ^ 2 — so q and the cached k come out bit-identical whichever tile a launch picks (batch-size invariance)
                     float sj[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) sj[j] = (v[j][0] * v[j][0] + v[j][1] * v[j][1]) + (v[j][2] * v[j][2] + v[j][3] * v[j][3]);
-                    float w = (sj[0] + sj[2]) + (sj[1] + sj[3]);
-                    w = w + __shfl_xor(w, 32, 64);
-                    w = w + __shfl_xor(w, 16, 64);
-                    const float rn = (sect == 0 ? sm : 1.0f) / vm_max(vm_sqrt(w), 1e-12f);
+                    for (int j = 0; j < 4; ++j) {
+                        sj[j] = (v[j][0] * v[j][0] + v[j][1] * v[j][1]) + (v[j][2] * v[j][2] + v[j][3] * v[j][3]);
+                        sj[j] = sj[j] + __shfl_xor(sj[j], 16, 64);                 // kq ^ 1  (the staged layout's lane ^ 1)
+                        sj[j] = sj[j] + __shfl_xor(sj[j], 32, 64);                 // kq ^ 2  (lane ^ 2)
+                    }
+                    const float w = (sj[0] + sj[1]) + (sj[2] + sj[3]);             // j ^ 1 (lane ^ 4), then j ^ 2 (lane ^ 8)
+                    const float rn = vh16_qk_rn(w, sect == 0 ? sm : 1.0f);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = v[j] * rn;
                 } else if (!p.q_l2 && sect == 0) {
@@ -385,6 +403,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm16p(Gemm16P p) {
     const int xq = nwg >> 3, xrem = nwg & 7, xcd = bid & 7, loc = bid >> 3;
     const int share = xq + (xcd < xrem ? 1 : 0), start = xcd < xrem ? xcd * (xq + 1) : xrem * (xq + 1) + (xcd - xrem) * xq;
     if (loc >= share) return;
+    if ((p.dbg >> 8) && (loc & 1)) for (int i = 0; i < (p.dbg >> 8); ++i) __builtin_amdgcn_s_sleep(127);
     auto tile_of = [&](int lin, int& m0, int& n0) {
         const int GM = 8, width = GM * p.tilesN, group = lin / width, first = group * GM;
         const int gsz = (p.tilesM - first) < GM ? (p.tilesM - first) : GM;
@@ -421,7 +440,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm16p(Gemm16P p) {
         if (has_next) tile_of(lin + per_xcd, nm0, nn0);
         // the prefetched first K tile of this tile has landed: it is older than every store of the previous epilogue (32 per wave when that
         // was the full-tile epilogue: a counted wait leaves them in flight; otherwise drain)
-        if (idx != loc) vh16_waitcnt_barrier<32>(); else vh16_waitcnt_barrier<0>();
+        if (idx != loc && !(p.dbg & 3)) vh16_waitcnt_barrier<32>(); else vh16_waitcnt_barrier<0>();
         f32x4 acc[TMW][TNW];
 #pragma unroll
         for (int i = 0; i < TMW; ++i)
@@ -460,7 +479,13 @@ __global__ void __launch_bounds__(512, 2) k_gemm16p(Gemm16P p) {
         }
         // ---- epilogue of tile (m0, n0): parks in the stage just read (st ^ 1) + the spare; stage st holds / receives the next tile
         char* const parkbase = smem16 + ((st ^ 1) ? G16P_STAGE : 0);
-        {   // (full tiles only: the host sends M % 256 rows and GEMMs with N % 256 != 0 to the one-tile kernels)
+        if (p.dbg & 2) {
+#pragma unroll
+            for (int i = 0; i < TMW; ++i)
+#pragma unroll
+                for (int j = 0; j < TNW; ++j) asm volatile("" :: "v"(acc[i][j]));
+        }
+        else {   // (full tiles only: the host sends M % 256 rows and GEMMs with N % 256 != 0 to the one-tile kernels)
             constexpr int SROW = BN * 4 + 64;
             static_assert(2 * 32 * SROW <= G16P_STAGE + G16P_SPARE, "two parking areas");
             const int n = n0 + lane * 4;
@@ -491,17 +516,15 @@ __global__ void __launch_bounds__(512, 2) k_gemm16p(Gemm16P p) {
                     f32x4 v = *(const f32x4*)(park + sr * SROW + lane * 16) + b4;
                     if (p.epi == 3) {
                         if (p.q_l2 && sect < 2) {
-                            float ss = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-#pragma unroll
-                            for (int off = 8; off >= 1; off >>= 1) ss = ss + __shfl_xor(ss, off, 64);
-                            v = v * ((sect == 0 ? sm : 1.0f) / vm_max(vm_sqrt(ss), 1e-12f));
+                            const float ss = vh16_sum16((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));      // a head = 16 lanes x 4 columns
+                            v = v * vh16_qk_rn(ss, sect == 0 ? sm : 1.0f);
                         } else if (!p.q_l2 && sect == 0) v = v * p.q_plain;
                         _Float16* dst;
                         const int ma = p.m_base + m;
                         if (sect == 0) dst = p.q_out + (int64_t)ma * Cq + head * 64;
                         else { const int bb = ma / p.q_l, t = ma - bb * p.q_l; dst = (sect == 1 ? p.q_kc : p.q_vc) + (((int64_t)bb * Hh + head) * p.q_Lmax + p.q_pos0 + t) * 64; }
                         h4 o; o[0] = (_Float16)v[0]; o[1] = (_Float16)v[1]; o[2] = (_Float16)v[2]; o[3] = (_Float16)v[3];
-                        *(h4*)(dst + (lane & 15) * 4) = o;
+                        if (!(p.dbg & 1)) *(h4*)(dst + (lane & 15) * 4) = o;
                         continue;
                     }
                     if (p.epi == VARHIP_EPI_GELU) { v[0] = vh16_gelu(v[0]); v[1] = vh16_gelu(v[1]); v[2] = vh16_gelu(v[2]); v[3] = vh16_gelu(v[3]); }
@@ -511,6 +534,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm16p(Gemm16P p) {
                                            v[0] = (float)r4[0] + v[0]; v[1] = (float)r4[1] + v[1]; v[2] = (float)r4[2] + v[2]; v[3] = (float)r4[3] + v[3]; }
                         else v = rcur[rr] + v;
                     }
+                    if (p.dbg & 1) { asm volatile("" :: "v"(v)); continue; }
                     if (p.out_f16) { h4 o; o[0] = (_Float16)v[0]; o[1] = (_Float16)v[1]; o[2] = (_Float16)v[2]; o[3] = (_Float16)v[3];
                                      *(h4*)(Ob + ((int64_t)m * p.ldo + n) * 2) = o; }
                     else *(f32x4*)(Ob + ((int64_t)m * p.ldo + n) * 4) = v;
@@ -534,6 +558,8 @@ static int g_gemm16_persist = [] { const char* e = getenv("VARHIP_GEMM16_PERSIST
 extern "C" int varhip_gemm16_persistent(int on) { g_gemm16_persist = on ? 1 : 0; return 0; }
 
 static int launch16p(Gemm16P& p, int batch, hipStream_t stream) {
+    static const int dbg = [] { const char* e = getenv("VARHIP_GEMM16_DBG"); return e ? atoi(e) : 0; }();      // experiments only
+    p.dbg = dbg;
     constexpr size_t lds = 2 * (size_t)G16P_STAGE + G16P_SPARE;
     p.tilesM = (p.M + 255) / 256; p.tilesN = (p.N + 255) / 256;
     static int ncu = 0;

@@ -143,7 +143,7 @@ class DecoderEngine(_VaeOps):
         """fp16 copies of every conv kernel (3x3, phase, 1x1 shortcut) next to the fp32 ones; biases and GroupNorm affine stay fp32"""
         if not self.w16:
             self.w16 = {k: v.to(torch.float16).contiguous() for k, v in self.w.items()
-                        if (k.endswith('.weight') or k.endswith('.phase')) and v.dim() >= 2 and '.attn' not in k}
+                        if (k.endswith('.weight') or k.endswith('.phase')) and v.dim() >= 2 and '.norm' not in k}
 
     # -- building blocks ---------------------------------------------------------------------------------------------
     def _part_buffer(self, B, nblk, Cout, dev):
@@ -282,13 +282,39 @@ class DecoderEngine(_VaeOps):
         return self.conv3_16(hn, pre + '.conv2', B, Hh, Ww, resid=sc, stats=True)
 
     def attnblock16(self, x, pre, B, Hh, Ww):
-        """the four single-head attention blocks at 16x16 (0.5 GMAC each) run in fp32 between two casts"""
-        x32 = torch.empty(x.shape, dtype=torch.float32, device=x.device)
-        hip.call('cast_f16_to_f32', x, x32, x.numel())
-        self._gn_part = None
-        y32 = self.attnblock(x32, pre, B, Hh, Ww)
-        y = torch.empty(x.shape, dtype=torch.float16, device=x.device)
-        hip.call('cast_f32_to_f16', y32, y, y.numel())
+        """AttnBlock (basic_vae.py:73-92) on fp16 activations: the five products (q/k projection, V^T projection, q.k^T, p.v, proj_out + residual)
+        on the f16 MFMA GEMM with fp32 accumulation; scores and softmax in fp32, the probabilities rounded to fp16 for p.v"""
+        HW, Cc = Hh * Ww, x.shape[-1]
+        dev = x.device
+        f16 = torch.float16
+        if Cc % 64 or HW % 64:                     # (tiny test configurations: the f16 GEMM contracts 64 at a time) fp32 attention between two casts
+            x32 = torch.empty(x.shape, dtype=torch.float32, device=dev)
+            hip.call('cast_f16_to_f32', x, x32, x.numel())
+            self._gn_part = None
+            y32 = self.attnblock(x32, pre, B, Hh, Ww)
+            y = torch.empty(x.shape, dtype=f16, device=dev)
+            hip.call('cast_f32_to_f16', y32, y, y.numel())
+            return y
+        xn = self.gn16(x, pre + '.norm', B, HW, False).view(B * HW, Cc)
+        wqkv, bqkv = self.w16[pre + '.qkv.weight'], self.w[pre + '.qkv.bias']
+        g16 = lambda A, lda, W, ldw, bias, out, ldo, o16, M, N, K, epi=EPI_NONE, resid=None, ldr=0, r16=0, batch=1, sA=0, sW=0, sO=0: \
+            hip.call('gemm_nt_f16', A, lda, W, ldw, bias, out, ldo, o16, M, N, K, epi, resid, ldr, r16, None, 0, 1, batch, sA, sW, sO)
+        qk = torch.empty((B * HW, 2 * Cc), dtype=f16, device=dev)
+        g16(xn, Cc, wqkv, Cc, bqkv, qk, 2 * Cc, 1, B * HW, 2 * Cc, Cc)
+        # V^T[b][c][j] WITHOUT its bias: the GEMM's bias is per column and here c is the row.  The rows of p sum to one, so the bias is added
+        # to p.v instead (column c of that product) — equal up to the fp16 rounding of p (|sum p - 1| <= 1e-3, bias ~1e-2: 1e-5)
+        vt = torch.empty((B, Cc, HW), dtype=f16, device=dev)
+        g16(wqkv[2 * Cc:], Cc, xn, Cc, None, vt, HW, 1, Cc, HW, Cc, batch=B, sA=0, sW=HW * Cc, sO=Cc * HW)
+        s = torch.empty((B, HW, HW), dtype=torch.float32, device=dev)
+        g16(qk, 2 * Cc, qk[:, Cc:], 2 * Cc, None, s, HW, 0, HW, HW, Cc, batch=B, sA=HW * 2 * Cc, sW=HW * 2 * Cc, sO=HW * HW)
+        p32 = torch.empty_like(s)
+        hip.call('softmax_rows_f32', s, p32, B * HW, HW, float(np.float32(int(Cc) ** (-0.5))))
+        p = torch.empty((B, HW, HW), dtype=f16, device=dev)
+        hip.call('cast_f32_to_f16', p32, p, p.numel())
+        o = torch.empty((B * HW, Cc), dtype=f16, device=dev)
+        g16(p, HW, vt, HW, bqkv[2 * Cc:], o, Cc, 1, HW, Cc, HW, batch=B, sA=HW * HW, sW=Cc * HW, sO=HW * Cc)
+        y = torch.empty((B, Hh, Ww, Cc), dtype=f16, device=dev)
+        g16(o, Cc, self.w16[pre + '.proj_out.weight'], Cc, self.w[pre + '.proj_out.bias'], y, Cc, 1, B * HW, Cc, Cc, epi=EPI_RESID, resid=x, ldr=Cc, r16=1)
         return y
 
     def _decode16(self, f_hat: torch.Tensor, denorm: bool) -> torch.Tensor:
