@@ -63,7 +63,10 @@ __device__ __forceinline__ float vh16_sum16(float v) {
 // 2x4 waves with TMW = 8, TNW = 4: the 256x256 tile (one workgroup of 8 waves per CU, 128 KB of LDS): a K tile step then moves 64 KB
 // for 8.4 MFLOP = 128 FLOP per L2->LDS byte, twice the 128x128 tile's — at the f16 MFMA rate the smaller tile is bound by what the
 // L2s can deliver.
-template <int TMW, int TNW, int WM = 2, int WN = 2>
+// NST: LDS stages.  2: a K tile is requested half a K step before it is waited for (vmcnt(0) + barrier per K tile).  3 / 4 (the 64-row tiles
+// of the small and middle scales, whose launches were bound by one request round trip per K tile — 16 of them in a row at K = 1024): NST - 1
+// K tiles in flight, counted vmcnt, the request for K tile kt + NST - 1 goes out right behind the barrier that frees its stage.
+template <int TMW, int TNW, int WM = 2, int WN = 2, int NST = 2>
 __global__ void __launch_bounds__(64 * WM * WN, 2) k_gemm16(Gemm16P p) {
     constexpr int NWAVE = WM * WN, BM = TMW * 16 * WM, BN = TNW * 16 * WN, ROWB = 128, STAGE = (BM + BN) * ROWB;      // bytes
     constexpr int NIA = BM / NWAVE / 8, NIB = BN / NWAVE / 8;                              // DMA instructions (8 rows x 128 B) per wave and K tile
@@ -162,6 +165,24 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) k_gemm16(Gemm16P p) {
             }
         }
     };
+    if constexpr (NST > 2) {
+        static_assert(TMW * TNW <= 16 && NST <= 4, "deep pipeline: the small wave tiles only");
+        constexpr int NDMA = NIA + NIB;                 // requests per wave and K tile
+#pragma unroll
+        for (int s2 = 0; s2 < NST - 1; ++s2) if (s2 < nk) dma_tile(s2, s2);
+#pragma unroll 1
+        for (int kt = 0; kt < nk; ++kt) {
+            // K tile kt has landed: everything older than the (up to NST - 2) younger tiles already requested
+            const int ahead = (nk - 1 - kt) < (NST - 2) ? (nk - 1 - kt) : (NST - 2);
+            if (ahead == 0) vh16_waitcnt_barrier<0>();
+            else if (ahead == 1) vh16_waitcnt_barrier<NDMA>();
+            else vh16_waitcnt_barrier<2 * NDMA>();
+            // stage (kt - 1) % NST was read in the previous K step, which every wave has left: refill it
+            if (kt + NST - 1 < nk) dma_tile(kt + NST - 1, (kt + NST - 1) % NST);
+            if (!idle_wave) compute(kt % NST, [] {});
+        }
+        vh16_waitcnt_barrier<0>();                      // the epilogue stages through the same LDS
+    } else {
     dma_tile(0, 0);
     vh16_waitcnt_barrier<0>();
     if (idle_wave) {
@@ -187,6 +208,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) k_gemm16(Gemm16P p) {
             if (kt < nk) { compute(0, [] {}); vh16_waitcnt_barrier<0>(); }
         }
     }
+    }
 
     // ---- epilogue: acc[i][j][e] = C[m = tile_m(i) + r16][n = tile_n(j) + 4*kq + e]
     if constexpr (NWAVE == 8 && TNW == 4) {
@@ -195,7 +217,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) k_gemm16(Gemm16P p) {
         // accesses cost more than the K loop of a K = 1024 GEMM.  Pass i: every wave parks its 16 rows x 64 columns, then wave w takes rows
         // 4w .. 4w+3 of the 32 parked rows: lane = 4 consecutive columns, so a row is one 1 KiB (fp32) / 512 B (fp16) access.
         if (m0 + BM <= p.M && n0 + BN <= p.N) {
-            constexpr int SROW = BN * 4 + 64;                          // bytes per parked row: 256 floats + pad (the stages are free: the K loop ended on a barrier)
+            constexpr int SROW = BN * 4 + 16;                          // bytes per parked row: 256 floats + 16 (a ds_write_b128 serves 8 lanes = 8 rows at a time: row stride = 4 banks mod 32, conflict-free; + 64 was 4-way)
             const int n = n0 + lane * 4;
             const f32x4 b4 = p.bias ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
             int sect = 0, head = 0, Cq = 0, Hh = 0; float sm = 1.0f;
@@ -263,7 +285,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) k_gemm16(Gemm16P p) {
     const int nw0 = n0 + wn * TNW * 16;
     if (nw0 >= p.N || m0 + wm * TMW * 16 >= p.M) return;
     constexpr int SROWW = TNW * 64 + 16, STGW = 16 * SROWW, NC = TNW * 4, RPI = 64 / NC, NIT = 16 / RPI;
-    static_assert((size_t)NWAVE * STGW <= (size_t)2 * STAGE, "epilogue staging must fit in the stages");
+    static_assert((size_t)NWAVE * STGW <= (size_t)NST * STAGE, "epilogue staging must fit in the stages");
     char* const stg = smem16 + wave * STGW;
     const int col = lane % NC, rl = lane / NC, n = nw0 + col * 4;
     const bool n_ok = n < p.N;                                      // (N % 4 == 0: host-checked)
@@ -486,7 +508,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm16p(Gemm16P p) {
                 for (int j = 0; j < TNW; ++j) asm volatile("" :: "v"(acc[i][j]));
         }
         else {   // (full tiles only: the host sends M % 256 rows and GEMMs with N % 256 != 0 to the one-tile kernels)
-            constexpr int SROW = BN * 4 + 64;
+            constexpr int SROW = BN * 4 + 16;              // (row stride = 4 banks mod 32: the parking ds_write_b128 of 8 rows are conflict-free)
             static_assert(2 * 32 * SROW <= G16P_STAGE + G16P_SPARE, "two parking areas");
             const int n = n0 + lane * 4;
             const f32x4 b4 = p.bias ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -578,18 +600,20 @@ static int launch16p(Gemm16P& p, int batch, hipStream_t stream) {
     return vh_launch_status();
 }
 
-template <int TMW, int TNW, int WM = 2, int WN = 2>
+template <int TMW, int TNW, int WM = 2, int WN = 2, int NST = 2>
 static int launch16(Gemm16P& p, int batch, hipStream_t stream) {
     constexpr int BM = TMW * 16 * WM, BN = TNW * 16 * WN;
-    constexpr size_t lds = 2 * (size_t)(BM + BN) * 128;
+    constexpr size_t lds = NST * (size_t)(BM + BN) * 128;
+    static_assert(lds <= 80 * 1024 || NST == 2, "two workgroups per CU");
     p.tilesM = (p.M + BM - 1) / BM; p.tilesN = (p.N + BN - 1) / BN;
-    auto kfn = k_gemm16<TMW, TNW, WM, WN>;
+    auto kfn = k_gemm16<TMW, TNW, WM, WN, NST>;
     static bool attr_done = false;
     if (!attr_done) { if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
     hipLaunchKernelGGL(kfn, dim3(p.tilesM * p.tilesN, 1, batch), dim3(64 * WM * WN), lds, stream, p);
     return vh_launch_status();
 }
 
+static int g_gemm16_deep = [] { const char* e = getenv("VARHIP_GEMM16_DEEP"); return e ? (atoi(e) != 0) : 1; }();      // experiments: 0 = the 2-stage small tiles
 static int g_force_tile16 = -1;
 // testing / experiments: force the tile of the next varhip_gemm_nt_f16 / varhip_gemm_qkv_f16 calls (0: 128x128, 1: 64x64 (64x128 for q/k/v), 2: 256x256, -1: automatic)
 extern "C" int varhip_gemm16_force_tile(int tile) { g_force_tile16 = (tile >= 0 && tile <= 2) ? tile : -1; return 0; }
@@ -680,7 +704,7 @@ extern "C" int varhip_gemm_nt_f16(const void* A, int64_t lda, const void* W, int
     p.M = M; p.N = N; p.K = K; p.epi = epi; p.rows_per_group = rows_per_group > 0 ? rows_per_group : 1; p.out_f16 = out_f16; p.resid_f16 = resid_f16;
     return run_gemm16(p, batch, (hipStream_t)stream, false, epi == VARHIP_EPI_RESID && !resid_f16,
                       2.0 * K + (out_f16 ? 2.0 : 4.0) * N, 2.0 * (double)N * K,
-                      [](Gemm16P& q, int pick, int b, hipStream_t s) { return pick == 0 ? launch16<4, 4>(q, b, s) : launch16<2, 2>(q, b, s); });
+                      [](Gemm16P& q, int pick, int b, hipStream_t s) { return pick == 0 ? launch16<4, 4>(q, b, s) : (g_gemm16_deep ? launch16<2, 2, 2, 2, 4>(q, b, s) : launch16<2, 2>(q, b, s)); });
 }
 
 // mat_qkv in the 16-bit mode: fp16 x fp16 -> fp32 accumulators -> (+bias, q/k L2 norm, scale) in fp32 -> fp16 q and fp16 KV-cache rows
@@ -697,5 +721,5 @@ extern "C" int varhip_gemm_qkv_f16(const void* A, int64_t lda, const void* W, in
     p.q_smul = scale_mul; p.q_out = (_Float16*)q_out; p.q_kc = (_Float16*)kcache; p.q_vc = (_Float16*)vcache; p.q_plain = plain_scale;
     p.q_l2 = l2norm; p.q_l = l; p.q_pos0 = pos0; p.q_Lmax = Lmax;
     return run_gemm16(p, 1, (hipStream_t)stream, true, false, 2.0 * K + 2.0 * 3.0 * C, 2.0 * 3.0 * C * (double)K,
-                      [](Gemm16P& q, int pick, int b, hipStream_t s) { return pick == 0 ? launch16<4, 4>(q, b, s) : launch16<2, 4>(q, b, s); });
+                      [](Gemm16P& q, int pick, int b, hipStream_t s) { return pick == 0 ? launch16<4, 4>(q, b, s) : (g_gemm16_deep ? launch16<2, 4, 2, 2, 3>(q, b, s) : launch16<2, 4>(q, b, s)); });
 }
