@@ -48,6 +48,18 @@ __device__ __forceinline__ float vh16_gelu(float x) {
 // reciprocal square root (1 ulp; the fp16 rounding of q and k is 2^-11) — one instruction where sqrt + IEEE division took ~25
 __device__ __forceinline__ float vh16_qk_rn(float ss, float scale) { return scale * __builtin_amdgcn_rsqf(__builtin_fmaxf(ss, 1e-24f)); }
 
+// v + (v of lane ^ 16) / (v of lane ^ 32) on the row / half swaps of gfx950 (plain vector instructions; __shfl_xor is a ds_bpermute round
+// trip).  permlane16_swap(a, b) exchanges the odd 16-lane rows of a with the even rows of b: called on two copies of v it leaves, in every
+// lane, v in one result and the partner row's v in the other — their sum is the same sum in both partners (addition commutes).
+__device__ __forceinline__ float vh16_add_xor16(float v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float vh16_add_xor32(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // sum over the 16 lanes of a row group (every lane ends with the total), partners lane^1, ^2, ^4, ^8 in that order, on DPP moves (the
 // compiler's __shfl_xor goes through ds_bpermute: four dependent LDS round trips per row).  After the first two steps the four lanes of a quad
 // agree, so the half-row mirror (i <-> 7 - i) pairs quads exactly as lane^4 would, and the row mirror (i <-> 15 - i) as lane^8.
@@ -314,8 +326,8 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) k_gemm16(Gemm16P p) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         sj[j] = (v[j][0] * v[j][0] + v[j][1] * v[j][1]) + (v[j][2] * v[j][2] + v[j][3] * v[j][3]);
-                        sj[j] = sj[j] + __shfl_xor(sj[j], 16, 64);                 // kq ^ 1  (the staged layout's lane ^ 1)
-                        sj[j] = sj[j] + __shfl_xor(sj[j], 32, 64);                 // kq ^ 2  (lane ^ 2)
+                        sj[j] = vh16_add_xor16(sj[j]);                             // kq ^ 1  (the staged layout's lane ^ 1)
+                        sj[j] = vh16_add_xor32(sj[j]);                             // kq ^ 2  (lane ^ 2)
                     }
                     const float w = (sj[0] + sj[1]) + (sj[2] + sj[3]);             // j ^ 1 (lane ^ 4), then j ^ 2 (lane ^ 8)
                     const float rn = vh16_qk_rn(w, sect == 0 ? sm : 1.0f);
