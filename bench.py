@@ -44,10 +44,10 @@ PEAK_HBM_GBS = 8000.0
 FAMILY_PEAK = {'gemm': PEAK_F32_MFMA_TFLOPS, 'gemm_small': PEAK_F32_MFMA_TFLOPS, 'conv3x3': PEAK_F32_MFMA_TFLOPS, 'conv_small': PEAK_F32_MFMA_TFLOPS,
                'attn': PEAK_F32_MFMA_TFLOPS, 'gemm16': PEAK_F16_MFMA_TFLOPS, 'gemm16_small': PEAK_F16_MFMA_TFLOPS, 'conv16h': PEAK_F16_MFMA_TFLOPS,
                'conv16_small': PEAK_F16_MFMA_TFLOPS, 'attn16': PEAK_F16_MFMA_TFLOPS}
-# families that can dominate a step -> the kernel symbol behind them (gemm / conv3x3 / gemm16 / conv16h: exactly one symbol; the attention
+# families that can dominate a step -> the kernel symbol behind them (gemm / conv3x3 / gemm16 (the persistent 256x256 kernel) / conv16h: exactly one symbol; the attention
 # families: one template, 1-4 waves per workgroup by l)
 DOMINANT = {'f32': {'gemm': 'k_dma_gemm<4,4,false,2,false>', 'conv3x3': 'k_dma_gemm<4,5,true,2,false>', 'attn': 'k_attn_cached<NW>'},
-            'f16': {'gemm16': 'k_gemm16<8,4,2,4>', 'conv16h': 'k_conv16h<5,32>', 'attn16': 'k_attn16<NW>'}}
+            'f16': {'gemm16': 'k_gemm16p', 'conv16h': 'k_conv16h<5,32>', 'attn16': 'k_attn16<NW>'}}
 
 
 def run_mode(var, dtype, steps, warmup, args, world, step_fn, dist, hip, torch):

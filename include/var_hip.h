@@ -323,7 +323,7 @@ int varhip_cast_f16_to_f32(const void* in, float* out, int64_t n, varhip_stream_
  * instantiation k_dma_gemm<4,5,true,2,false>), 2 attn, 3 sampler, 4 ln, 5 qkv_prep, 6 gn, 7 other, 8 gemm_small (every other tile
  * of the transformer GEMMs and the element-wise-load fallback), 9 conv_small (every other conv tile: nearest-2x gather, Cout not
  * a multiple of 160); the 16-bit mode's kernels in families of their own (one arithmetic type, hence one MFMA peak, per family):
- * 10 gemm16 (k_gemm16<8,4,2,4>, the 256x256 tile), 11 gemm16_small (the other k_gemm16 tiles), 12 conv16h (k_conv16h<5,32>),
+ * 10 gemm16 (k_gemm16p, the persistent 256x256-tile kernel), 11 gemm16_small (every k_gemm16 tile), 12 conv16h (k_conv16h<5,32>),
  * 13 conv16_small (every other fp16 conv kernel), 14 attn16.  Families 0, 1, 10 and 12 each map to exactly one kernel symbol, so their
  * averages can be checked against a rocprofv3 kernel trace.  Returns the number of families. */
 #define VARHIP_NFAM 15

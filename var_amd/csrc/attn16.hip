@@ -15,8 +15,8 @@
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef __fp16 vf4 __attribute__((__vector_size__(4 * sizeof(__fp16))));      // the transposing LDS read's result type
 
-#define VLD16 40          // halves per V^T row: 32 keys + 8 pad (80 bytes: ds_read_b128 of 16 channel rows hits 16 different slots)
 #define OLD16 72          // halves per row of the output staging tile (64 + 8 pad)
 
 __device__ __forceinline__ void vh16a_dma16(const void* base, uint32_t voff, uint32_t lds) {
@@ -28,11 +28,11 @@ template <int NW>
 __global__ void __launch_bounds__(NW * 64, NW) k_attn16(const _Float16* __restrict__ q, const _Float16* __restrict__ kcache, const _Float16* __restrict__ vcache,
                                                          _Float16* __restrict__ out, int l, int H, int curL, int Lmax) {
     constexpr int NT = NW * 64, NIT = (256 + NT - 1) / NT;
-    constexpr int KST = 32 * 128, VST = 64 * VLD16 * 2;           // bytes per K / V stage
-    __shared__ __attribute__((aligned(16))) char smem[2 * KST + 2 * VST];
+    constexpr int KST = 32 * 128, VST = 32 * 128;                 // bytes per K / V stage (32 keys x 64 halves)
+    constexpr int OST = NW * 32 * OLD16 * 2;                      // bytes of the output staging tile (reuses the K / V stages)
+    __shared__ __attribute__((aligned(16))) char smem[(2 * KST + 2 * VST) > OST ? (2 * KST + 2 * VST) : OST];
     char* sK = smem;
     char* sV = smem + 2 * KST;
-    static_assert(4 * 32 * OLD16 * 2 <= 2 * KST + 2 * VST, "O staging must fit in the K/V stages");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h2 = lane >> 5;
@@ -64,27 +64,28 @@ __global__ void __launch_bounds__(NW * 64, NW) k_attn16(const _Float16* __restri
                         (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(sK + st * KST + n * 1024));
         }
     };
-    // V tile through registers: item = (key row, 8-channel chunk); stored transposed, V^T[channel][pos(key)] with
-    // pos(key) = 16 (key >> 4) + 8 ((key >> 2) & 1) + 4 ((key >> 3) & 1) + (key & 3): the 8 keys of (step s, half h) are contiguous at 16s + 8h
-    h8 gv[NIT];
-    auto load_v = [&](int kt) {
+    // V tile by LDS-DMA as well, ROW-major as it lies in the cache ([32 keys][64 channels], 128 B per key); the second product wants V^T
+    // fragments (lane = channel, 8 keys) — the transposing read ds_read_b64_tr_b16 delivers exactly that: per group of 16 lanes it reads a
+    // block of 4 key rows x 16 channels (lane 4q + p supplies the address of row q, channels 4p .. 4p + 3) and gives lane i channel i of the
+    // four rows.  Round 2 transposed in registers: 8 two-byte LDS stores per thread and tile, 8-way bank-conflicted.
+    // Slot c of row rr holds source chunk c ^ (((rr >> 1) & 1) << 2): the four rows of a block then sit on four different bank quarters.
+    auto dma_v = [&](int kt, int st) {
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int item = tid + it * NT, sr = item >> 3, sc = item & 7, key = kt * 32 + sr;
-            gv[it] = (h8)(_Float16)0.f;
-            if ((NIT * NT == 256 || item < 256) && key < curL) gv[it] = *(const h8*)(Vc + (int64_t)key * 64 + sc * 8);
+        for (int i = 0; i < (4 + NW - 1) / NW; ++i) {
+            const int n = wave + i * NW;
+            if (n >= 4) break;
+            const int rr = n * 8 + (lane >> 3);
+            int key = kt * 32 + rr; key = key < curL ? key : curL - 1;      // (keys past curL: their probabilities are exactly 0, any finite row serves)
+            vh16a_dma16(Vc, (uint32_t)key * 128u + (uint32_t)(((lane & 7) ^ (((rr >> 1) & 1) << 2)) << 4),
+                        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(sV + st * VST + n * 1024));
         }
     };
-    auto store_v = [&](int buf) {
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int item = tid + it * NT, sr = item >> 3, sc = item & 7;
-            if (NIT * NT != 256 && item >= 256) continue;
-            const int pos = ((sr >> 4) << 4) + (((sr >> 2) & 1) << 3) + (((sr >> 3) & 1) << 2) + (sr & 3);
-            _Float16* dv = (_Float16*)(sV + buf * VST) + (sc * 8) * VLD16 + pos;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) dv[e * VLD16] = gv[it][e];
-        }
+    // this lane's address inside a V stage for (step s, second half of the step's keys u, channel half c32): block rows = keys
+    // 16 s + 8 u + 4 h2 + q, q = (lane >> 2) & 3; channels 16 ((lane >> 4) & 1) + 4 (lane & 3) .. + 3 (+ 32 c32)
+    const int vq = (lane >> 2) & 3, vp = lane & 3, vg = (lane >> 4) & 1;
+    auto v_addr = [&](int st, int s2, int u, int c32) -> const char* {
+        const int row = 16 * s2 + 8 * u + 4 * h2 + vq, chunk = (2 * vg + (vp >> 1) + 4 * c32) ^ (((row >> 1) & 1) << 2);
+        return sV + st * VST + row * 128 + (chunk << 4) + (vp & 1) * 8;
     };
 
     f32x16 o0, o1;
@@ -92,13 +93,13 @@ __global__ void __launch_bounds__(NW * 64, NW) k_attn16(const _Float16* __restri
     for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; }
     float lsum = 0.f, mx = -INFINITY;                               // mx in units of log2: (max score) * log2(e)
     const float LOG2E = 1.44269504088896341f;
-    dma_k(0, 0); load_v(0); store_v(0);
+    dma_k(0, 0); dma_v(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int kxor = (r >> 1) & 7;
     for (int kt = 0; kt < ntile; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < ntile) { dma_k(kt + 1, buf ^ 1); load_v(kt + 1); }
+        if (kt + 1 < ntile) { dma_k(kt + 1, buf ^ 1); dma_v(kt + 1, buf ^ 1); }
         if (t0 < l) {
             f32x16 p;
             {
@@ -144,15 +145,20 @@ __global__ void __launch_bounds__(NW * 64, NW) k_attn16(const _Float16* __restri
             for (int s = 0; s < 2; ++s)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) pf[s][j] = (_Float16)p[8 * s + j];
-            const char* vb = sV + buf * VST + (r * VLD16 + h2 * 8) * 2;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const h8 v0 = *(const h8*)(vb + s * 32), v1 = *(const h8*)(vb + 32 * VLD16 * 2 + s * 32);     // channels r and r + 32
-                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, pf[s], o0, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, pf[s], o1, 0, 0, 0);
+                // V^T fragments of step s: elements 0..3 = keys 16s + 4h + 0..3, elements 4..7 = keys 16s + 8 + 4h + 0..3 (the order of pf)
+                h8 v0, v1;
+                const vf4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) vf4*)v_addr(buf, s, 0, 0));
+                const vf4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) vf4*)v_addr(buf, s, 1, 0));
+                const vf4 c0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) vf4*)v_addr(buf, s, 0, 1));
+                const vf4 c1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) vf4*)v_addr(buf, s, 1, 1));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v0[e] = (_Float16)a0[e]; v0[4 + e] = (_Float16)a1[e]; v1[e] = (_Float16)c0[e]; v1[4 + e] = (_Float16)c1[e]; }
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, pf[s], o0, 0, 0, 0);      // channels r
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, pf[s], o1, 0, 0, 0);      // channels r + 32
             }
         }
-        if (kt + 1 < ntile) store_v(buf ^ 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }

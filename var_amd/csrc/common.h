@@ -53,7 +53,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define VH_FAM_GEMM_SMALL 8
 #define VH_FAM_CONV_SMALL 9
 // the 16-bit mode's kernels have families of their own: one arithmetic type (one MFMA peak) per family, and the three that can dominate a
-// step map to exactly one kernel symbol each (k_gemm16<8,4,2,4>, k_conv16h<5,32>, k_attn16<NW>)
+// step map to one kernel each (k_gemm16p, k_conv16h<5,32>, k_attn16<NW>)
 #define VH_FAM_GEMM16 10
 #define VH_FAM_GEMM16_SMALL 11
 #define VH_FAM_CONV16H 12

@@ -690,9 +690,11 @@ static int run_gemm16(Gemm16P& p, int batch, hipStream_t stream, bool qkv, bool 
             p.out = O0 + (int64_t)m0 * p.ldo * (p.out_f16 ? 2 : 4);
             p.resid = R0 ? R0 + (int64_t)m0 * p.ldr * (p.resid_f16 ? 2 : 4) : nullptr;
         }
-        VhScope scope(pick == 2 ? VH_FAM_GEMM16 : VH_FAM_GEMM16_SMALL, stream, 2.0 * rows * p.N * (double)p.K * batch,
+        const bool persistent = pick == 2 && persist_ok && (rows % 256) == 0;
+        // family "gemm16" = k_gemm16p alone (one symbol: its event average is comparable with a rocprofv3 trace); everything else "gemm16_small"
+        VhScope scope(persistent ? VH_FAM_GEMM16 : VH_FAM_GEMM16_SMALL, stream, 2.0 * rows * p.N * (double)p.K * batch,
                       batch * (rows * bytes_per_row + (i ? 0.0 : bytes_fixed)));
-        if (pick == 2) rc = (persist_ok && (rows % 256) == 0) ? launch16p(p, batch, stream) : launch16<8, 4, 2, 4>(p, batch, stream);
+        if (pick == 2) rc = persistent ? launch16p(p, batch, stream) : launch16<8, 4, 2, 4>(p, batch, stream);
         else rc = small_launch(p, pick, batch, stream);
     }
     p.M = M; p.m_base = 0; p.A = (const _Float16*)A0; p.out = O0; p.resid = R0;
