@@ -6,7 +6,7 @@ import os
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libvar_hip.so')
+LIB_PATH = os.environ.get('VARHIP_LIB') or os.path.join(_HERE, 'libvar_hip.so')      # (VARHIP_LIB: A/B experiments against another build of the library)
 
 
 class VarHipError(RuntimeError):
