@@ -82,15 +82,9 @@ def run_mode(var, dtype, steps, warmup, args, world, step_fn, dist, hip, torch):
     gather_ms = sum(a.elapsed_time(b) for a, b in gather_ev) / max(steps, 1)
     ranks = None
     if world > 1:
-        t = torch.tensor([dt, dt_own, gather_ms], device=img.device, dtype=torch.float64)
-        allt = [torch.empty_like(t) for _ in range(world)]
-        torch.distributed.all_gather(allt, t)
-        dt = max(float(x[0]) for x in allt)
-        ranks = {'rank_ms_min': round(min(float(x[1]) for x in allt) / steps * 1e3, 3), 'rank_ms_max': round(max(float(x[1]) for x in allt) / steps * 1e3, 3),
-                 'allgather_ms': round(max(float(x[2]) for x in allt), 3), 'allgather_ms_min': round(min(float(x[2]) for x in allt), 3),
-                 'allgather_mbytes': round(B_total * 3 * img.shape[2] * img.shape[3] * 4 / 1e6, 1),
-                 'note': 'rank_ms_*: each rank\'s own wall time per step for the timed region (sampling + decode + all-gather, before the closing barrier); '
-                         'allgather_ms: HIP-event time of the RCCL all-gather per step (max / min over ranks; a rank that arrives early waits inside it)'}
+        from var_amd.multi import rank_stats
+        rs = rank_stats(dt, dt_own, gather_ms, steps, img.shape, img.device)
+        dt, ranks = rs['dt_max'], rs['ranks']
     return dict(dt=dt, tt=tt, prepass=prepass, dominant=dominant, ranks=ranks, steps=steps, warmup=warmup, dtype=dtype)
 
 

@@ -234,6 +234,14 @@ else:
     lo, hi = multi.shard_range(B, dist.get_rank(), 2)
     mine = multi.sample_sharded(FakeVar, B, labels, g_seed=5, rng_mode='per_rank', sample_fn=fake_sample, gather=False)
     assert torch.equal(out[lo:hi], mine) and out.shape[0] == B
+# bench.py's N > 1 statistics: job time = max over ranks, per-rank own time min / max, all-gather time max / min
+r = dist.get_rank()
+rs = multi.rank_stats(dt=2.0 + r, dt_own=1.0 + 0.5 * r, gather_ms=3.0 - r, steps=2, gathered_shape=(B, 3, 2, 2), device='cpu')
+assert rs['dt_max'] == 3.0 and rs['ranks']['rank_ms_min'] == 500.0 and rs['ranks']['rank_ms_max'] == 750.0, rs
+assert rs['ranks']['allgather_ms'] == 3.0 and rs['ranks']['allgather_ms_min'] == 2.0 and abs(rs['ranks']['allgather_mbytes'] - B * 12 * 4 / 1e6) < 0.05, rs
+ev = []
+out2 = multi.sample_sharded(FakeVar, B, labels, g_seed=5, rng_mode=mode, sample_fn=fake_sample, gather_events=ev)      # CPU tensors: no events, same result
+assert torch.equal(out2, out) and ev == []
 tdist.barrier()
 print('rank', dist.get_rank(), 'ok')
 '''

@@ -67,3 +67,23 @@ def sample_sharded(var, B_total: int, label_B: torch.Tensor, g_seed: Optional[in
     b.record()
     gather_events.append((a, b))
     return out
+
+
+def rank_stats(dt: float, dt_own: float, gather_ms: float, steps: int, gathered_shape, device) -> dict:
+    """bench.py, N > 1: one all-gather of (elapsed time to the closing barrier, this rank's own elapsed time, all-gather ms per step) over the
+    ranks -> the job's time (max) and the `ranks` object of the bench line: the spread a scaling run needs to be diagnosed (a slow rank shows in
+    rank_ms_max; ranks that arrive early wait inside the all-gather, so allgather_ms max - min is the arrival skew)."""
+    import torch.distributed as tdist
+    world = dist.get_world_size()
+    t = torch.tensor([dt, dt_own, gather_ms], device=device, dtype=torch.float64)
+    allt = [torch.empty_like(t) for _ in range(world)]
+    tdist.all_gather(allt, t)
+    rows = [[float(v) for v in x.cpu()] for x in allt]
+    nbytes = 4
+    for d in gathered_shape: nbytes *= int(d)
+    return {'dt_max': max(r[0] for r in rows),
+            'ranks': {'rank_ms_min': round(min(r[1] for r in rows) / steps * 1e3, 3), 'rank_ms_max': round(max(r[1] for r in rows) / steps * 1e3, 3),
+                      'allgather_ms': round(max(r[2] for r in rows), 3), 'allgather_ms_min': round(min(r[2] for r in rows), 3),
+                      'allgather_mbytes': round(nbytes / 1e6, 1),
+                      'note': "rank_ms_*: each rank's own wall time per step for the timed region (sampling + decode + all-gather, before the closing barrier); "
+                              'allgather_ms: HIP-event time of the RCCL all-gather per step (max / min over ranks; a rank that arrives early waits inside it)'}}
