@@ -476,6 +476,37 @@ def test_f16_mode_vs_twin_and_reference(name):
     assert np.isfinite(free.cpu().numpy()).all()
 
 
+@pytest.mark.parametrize('name', ['ac16_t_pn12345', 'ac16_t_saln', 'ac16_d16_pn123'])
+def test_f16_mode_vs_reference_under_fp16_autocast(name):
+    """the 16-bit mode on the GPU against the REFERENCE's own 16-bit execution (fixtures: the reference's autoregressive_infer_cfg under
+    torch.autocast(dtype=float16), demo_sample.py:66-68), teacher-forced with the fixture's tokens: logits within 2e-3 x max|logit| (the
+    reference's logits carry an fp16 rounding of their own: 4e-3 at |logit| 8..16), token agreement >= 97 %, pixels within 2e-2"""
+    z, meta = util.load_case(name)
+    assert meta['autocast16'] is True
+    vae, var = _models(meta)
+    pns = meta['patch_nums']
+    noise = [torch.from_numpy(n) for n in util.regen_noise(meta, z)]
+    labels = torch.tensor(meta['labels'], dtype=torch.int64, device='cuda')
+    var.set_hip_precision('f16')
+    try:
+        eng = var.engine()
+        img = eng.sample(len(meta['labels']), labels, None, meta['cfg'], meta['top_k'], meta['top_p'], noises=noise,
+                         force_idx=torch.from_numpy(z['idx'].astype(np.int64)), trace=True).cpu().numpy()
+        tr = {k: [t.cpu().numpy() for t in v] for k, v in eng.last_trace.items()}
+    finally:
+        var.set_hip_precision('f32')
+    msgs, ok_all = [], True
+    for si, pn in enumerate(pns):
+        lg, want = tr['logits'][si], z[f'logits_s{si}']
+        got = lg if meta['full_logits'] else lg[:, sorted({0, pn * pn - 1}), :]
+        ok, m = util.diff_report(f'{name} f16 logits s{si} vs the reference under fp16 autocast', got, want, atol=2e-3 * max(float(np.abs(want).max()), 1.0)); ok_all &= ok; msgs.append(m)
+    agree = float((np.concatenate(tr['idx'], axis=1) == z['idx']).mean())
+    msgs.append(f'{name}: token agreement with the reference under fp16 autocast (teacher-forced) {agree:.3f}')
+    ok, m = util.diff_report(f'{name} f16 image vs the reference under fp16 autocast', img, z['img'], atol=2e-2); ok_all &= ok; msgs.append(m)
+    print('\n'.join(msgs))
+    assert ok_all and agree >= 0.97, '\n'.join(msgs)
+
+
 def test_f16_mode_properties_d16_full():
     """d16, all 10 scales at B=4 in the 16-bit mode: deterministic, batch-slice invariant, finite; the mode switch restores fp32 results bit for bit"""
     z, meta = util.load_case('d16_full')

@@ -257,3 +257,27 @@ def test_wide_model_fixtures(name):
     """the widths of BASELINE.json configs[3] (VAR-d30, C=1920) and configs[4] (VAR-d36, C=2304, shared AdaLN): oracle vs the
     reference's own run at full depth on the first scales; teacher-forced only"""
     _check_case(name, logit_atol=1e-3, img_atol=1e-3, free_running=False)
+
+
+@pytest.mark.parametrize('name', ['ac16_t_pn12345', 'ac16_t_saln', 'ac16_d16_pn123'])
+def test_f16_twin_vs_reference_under_fp16_autocast(name):
+    """The CPU twin of the 16-bit throughput mode (OracleVAR(f16=True): the fp32 restatement with rounding points) against the REFERENCE's own
+    16-bit execution: fixtures made by wrapping the reference's autoregressive_infer_cfg in torch.autocast(dtype=float16) as its harness does
+    (demo_sample.py:66-68; tools/gen_golden.py run_case(autocast16=True)).  Teacher-forced with the fixture's tokens.  The reference's logits
+    come out of an fp16 F.linear (half an fp16 ulp = 4e-3 at |logit| 8..16) and its matmuls round where ATen's CPU kernels round, so the bar
+    is a tolerance, stated here: logits within 2e-3 x max|logit| (measured: 8e-4), every token the reference sampled reproduced, pixels within 2e-2."""
+    z, meta = util.load_case(name)
+    assert meta['autocast16'] is True
+    var_sd, vae_sd = util.make_weights(meta)
+    twin = OracleVAR(var_sd, vae_sd, meta['patch_nums'], meta['depth'], attn_l2_norm=meta['attn_l2_norm'], shared_aln=meta['shared_aln'], f16=True)
+    r = twin.run(meta['labels'], util.regen_noise(meta, z), meta['cfg'], meta['top_k'], meta['top_p'], force_idx=z['idx'].astype(np.int64))
+    msgs, ok_all = [], True
+    for si, pn in enumerate(meta['patch_nums']):
+        lg, want = r['logits'][si], z[f'logits_s{si}']
+        got = lg if meta['full_logits'] else lg[:, sorted({0, pn * pn - 1}), :]
+        ok, m = util.diff_report(f'{name} twin logits s{si}', got, want, atol=2e-3 * max(float(np.abs(want).max()), 1.0)); ok_all &= ok; msgs.append(m)
+    agree = float((r['idx'] == z['idx']).mean())
+    msgs.append(f'{name}: twin tokens == reference-under-autocast tokens (teacher-forced): {agree:.3f}')
+    ok, m = util.diff_report(f'{name} image', r['img'], z['img'], atol=2e-2); ok_all &= ok; msgs.append(m)
+    print('\n'.join(msgs))
+    assert ok_all and agree >= 0.97, '\n'.join(msgs)

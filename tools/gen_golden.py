@@ -73,7 +73,10 @@ def build_reference(cfg, init_seed=0):
     return vae.eval(), var.eval()
 
 
-def run_case(name, cfg):
+def run_case(name, cfg, autocast16=False):
+    """autocast16: the reference's own 16-bit execution — the call wrapped in torch.autocast(dtype=float16) exactly as demo_sample.py:66-68 does
+    (device 'cpu' here: F.linear / conv2d / SDPA run on fp16 operands with fp16 results, LayerNorm / softmax / get_logits' .float() in fp32).
+    These fixtures pin the 16-bit throughput mode (and its CPU twin) against the reference itself, with a tolerance."""
     vae, var = build_reference(cfg)
     pns = tuple(cfg['patch_nums'])
     B = len(cfg['labels'])
@@ -98,13 +101,15 @@ def run_case(name, cfg):
     quant.get_next_autoregressive_input = get_next
 
     t0 = time.time()
-    with torch.inference_mode():
+    import contextlib
+    with torch.inference_mode(), (torch.autocast('cpu', dtype=torch.float16) if autocast16 else contextlib.nullcontext()):
         img = var.autoregressive_infer_cfg(B, torch.tensor(cfg['labels'], dtype=torch.long), g_seed=cfg['seed'], cfg=cfg['cfg'],
                                            top_k=cfg['top_k'], top_p=cfg['top_p'], more_smooth=False)
     dt = time.time() - t0
     hk.remove()
+    logits[:] = [x.float() for x in logits]; fhats[:] = [x.float() for x in fhats]; pools[:] = [x.float() for x in pools]
 
-    rec['img'] = img.numpy().astype(np.float32)
+    rec['img'] = img.float().numpy().astype(np.float32)
     rec['idx'] = torch.cat(idxs, dim=1).numpy().astype(np.int32)
     lsum, labs = [], []
     for si, pn in enumerate(pns):
@@ -125,6 +130,7 @@ def run_case(name, cfg):
     rec['noise_head'] = np.stack(nh); rec['noise_sum'] = np.array(ns)
     meta = dict(cfg); meta['B'] = B; meta['V'] = int(V); meta['ref_seconds'] = dt; meta['torch'] = torch.__version__
     meta['threads'] = torch.get_num_threads()
+    meta['autocast16'] = bool(autocast16)
     rec['meta'] = np.array(json.dumps(meta))
     np.savez_compressed(os.path.join(GOLD, f'e2e_{name}.npz'), **rec)
     print(f'[gen_golden] {name}: {dt:.2f}s  img mean {img.mean():.4f}  tokens {rec["idx"].shape}', flush=True)
@@ -378,6 +384,8 @@ def main():
     for name, cfg in CASES.items():
         if args.only and name not in args.only: continue
         run_case(name, cfg)
+    for base in ('t_pn12345', 't_saln', 'd16_pn123'):                 # the reference under its harness' fp16 autocast (demo_sample.py:66-68)
+        if not args.only or ('ac16_' + base) in args.only: run_case('ac16_' + base, CASES[base], autocast16=True)
     if not args.only or 'inpaint' in args.only: run_inpaint()
     if not args.only or 'more_smooth' in args.only: run_more_smooth()
     if not args.only or 'inpaint_more_smooth' in args.only: run_inpaint_more_smooth()
