@@ -14,7 +14,6 @@ Differences from the reference's schedule (results unchanged):
 from __future__ import annotations
 
 import math
-import os
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -189,24 +188,12 @@ class DecoderEngine(_VaeOps):
                  resid, N, None, 0, 1, 0, 1, 0, 0, 0)
         return out
 
-    @staticmethod
-    def _drain(gen):
-        """run a step generator (below) to its end on the current stream; returns its value"""
-        try:
-            while True: next(gen)
-        except StopIteration as e:
-            return e.value
-
     def resblock(self, x, pre, B, Hh, Ww):
-        """ResnetBlock (basic_vae.py:57-60) as a STEP GENERATOR: it yields after every launch group (a GroupNorm, a conv), so that
-        decode_nhwc can interleave two halves of a batch on two streams (a half's memory-bound GroupNorm beside the other half's conv)"""
         HW = Hh * Ww
-        a = self.gn(x, pre + '.norm1', B, HW, True); yield
-        h = self.conv3(a, pre + '.conv1', B, Hh, Ww, stats=True); yield                                        # -> norm2
-        hn = self.gn(h, pre + '.norm2', B, HW, True); yield
+        h = self.conv3(self.gn(x, pre + '.norm1', B, HW, True), pre + '.conv1', B, Hh, Ww, stats=True)        # -> norm2
+        hn = self.gn(h, pre + '.norm2', B, HW, True)
         sc = self.lin(x.view(B * HW, -1), pre + '.nin_shortcut').view(B, Hh, Ww, -1) if (pre + '.nin_shortcut.weight') in self.w else x
-        out = self.conv3(hn, pre + '.conv2', B, Hh, Ww, resid=sc, stats=True); yield                           # -> the next block's norm
-        return out
+        return self.conv3(hn, pre + '.conv2', B, Hh, Ww, resid=sc, stats=True)                                  # -> the next block's norm
 
     def attnblock(self, x, pre, B, Hh, Ww):
         HW, Cc = Hh * Ww, x.shape[-1]
@@ -283,19 +270,16 @@ class DecoderEngine(_VaeOps):
         return out
 
     def resblock16(self, x, pre, B, Hh, Ww):
-        """step generator, as resblock"""
         HW = Hh * Ww
-        a = self.gn16(x, pre + '.norm1', B, HW, True); yield
-        h = self.conv3_16(a, pre + '.conv1', B, Hh, Ww, stats=True); yield
-        hn = self.gn16(h, pre + '.norm2', B, HW, True); yield
+        h = self.conv3_16(self.gn16(x, pre + '.norm1', B, HW, True), pre + '.conv1', B, Hh, Ww, stats=True)
+        hn = self.gn16(h, pre + '.norm2', B, HW, True)
         sc = x
         if (pre + '.nin_shortcut.weight') in self.w16:              # 1x1 conv == fp16 GEMM over the pixels
             wt = self.w16[pre + '.nin_shortcut.weight']
             N, K = wt.shape
             sc = torch.empty((B, Hh, Ww, N), dtype=torch.float16, device=x.device)
             hip.call('gemm_nt_f16', x, K, wt, K, self.w[pre + '.nin_shortcut.bias'], sc, N, 1, B * HW, N, K, EPI_NONE, None, 0, 0, None, 0, 1, 1, 0, 0, 0)
-        out = self.conv3_16(hn, pre + '.conv2', B, Hh, Ww, resid=sc, stats=True); yield
-        return out
+        return self.conv3_16(hn, pre + '.conv2', B, Hh, Ww, resid=sc, stats=True)
 
     def attnblock16(self, x, pre, B, Hh, Ww):
         """AttnBlock (basic_vae.py:73-92) on fp16 activations: the five products (q/k projection, V^T projection, q.k^T, p.v, proj_out + residual)
@@ -333,22 +317,21 @@ class DecoderEngine(_VaeOps):
         g16(o, Cc, self.w16[pre + '.proj_out.weight'], Cc, self.w[pre + '.proj_out.bias'], y, Cc, 1, B * HW, Cc, Cc, epi=EPI_RESID, resid=x, ldr=Cc, r16=1)
         return y
 
-    def _decode16(self, f_hat: torch.Tensor, denorm: bool):
-        """step generator (see resblock): the decoder on fp16 activations"""
+    def _decode16(self, f_hat: torch.Tensor, denorm: bool) -> torch.Tensor:
         B, P = f_hat.shape[0], f_hat.shape[1]
         Hh = Ww = P
         x = torch.empty(f_hat.shape, dtype=torch.float16, device=f_hat.device)
         hip.call('cast_f32_to_f16', f_hat.contiguous(), x, x.numel())
-        h = self.conv3_16(x, 'post_quant_conv', B, Hh, Ww); yield
-        h = self.conv3_16(h, 'decoder.conv_in', B, Hh, Ww, stats=True); yield
-        h = yield from self.resblock16(h, 'decoder.mid.block_1', B, Hh, Ww)
-        h = self.attnblock16(h, 'decoder.mid.attn_1', B, Hh, Ww); yield
-        h = yield from self.resblock16(h, 'decoder.mid.block_2', B, Hh, Ww)
+        h = self.conv3_16(x, 'post_quant_conv', B, Hh, Ww)
+        h = self.conv3_16(h, 'decoder.conv_in', B, Hh, Ww, stats=True)
+        h = self.resblock16(h, 'decoder.mid.block_1', B, Hh, Ww)
+        h = self.attnblock16(h, 'decoder.mid.attn_1', B, Hh, Ww)
+        h = self.resblock16(h, 'decoder.mid.block_2', B, Hh, Ww)
         for lev in reversed(range(self.nlev)):
             for ib in range(3):
-                h = yield from self.resblock16(h, f'decoder.up.{lev}.block.{ib}', B, Hh, Ww)
+                h = self.resblock16(h, f'decoder.up.{lev}.block.{ib}', B, Hh, Ww)
                 if f'decoder.up.{lev}.attn.{ib}.norm.weight' in self.w:
-                    h = self.attnblock16(h, f'decoder.up.{lev}.attn.{ib}', B, Hh, Ww); yield
+                    h = self.attnblock16(h, f'decoder.up.{lev}.attn.{ib}', B, Hh, Ww)
             if lev != 0:
                 Hh, Ww = 2 * Hh, 2 * Ww
                 key = f'decoder.up.{lev}.upsample.conv'
@@ -358,24 +341,30 @@ class DecoderEngine(_VaeOps):
                 part = self._part_buffer(B, nblk, wp.shape[1], h.device) if nblk else None
                 hip.call('upconv_phase_f16', h, wp, self.w[key + '.bias'], up, part, B, Hh, Ww, wp.shape[4], wp.shape[1])
                 self._gn_part = (up, part, nblk) if nblk else None
-                h = up; yield
-        h = self.gn16(h, 'decoder.norm_out', B, Hh * Ww, True); yield
+                h = up
+        h = self.gn16(h, 'decoder.norm_out', B, Hh * Ww, True)
         return self.conv3_16(h, 'decoder.conv_out', B, Hh, Ww, out_mode=1 if denorm else 2)
 
-    def _decode32(self, f_hat: torch.Tensor, denorm: bool):
-        """step generator: the fp32 decoder (Decoder.forward, basic_vae.py:210-226)"""
+    def decode_nhwc(self, f_hat: torch.Tensor, denorm: bool = True, precision: Optional[str] = None) -> torch.Tensor:
+        """[B,P,P,Cvae] channels-last -> [B,3,16P,16P]; denorm=True: in [0,1] (clamp and (x+1)/2 fused into the last conv, what
+        autoregressive_infer_cfg returns); denorm=False: clamped to [-1,1] (VQVAE.fhat_to_img's contract).
+        precision: 'f32' / 'f16' for THIS call (None: the engine's default, `self.precision`)"""
+        self.refresh()
+        if (precision or self.precision) == 'f16':
+            self._ensure16()
+            return self._decode16(f_hat, denorm)
         B, P = f_hat.shape[0], f_hat.shape[1]
         Hh = Ww = P
-        h = self.conv3(f_hat, 'post_quant_conv', B, Hh, Ww); yield
-        h = self.conv3(h, 'decoder.conv_in', B, Hh, Ww, stats=True); yield
-        h = yield from self.resblock(h, 'decoder.mid.block_1', B, Hh, Ww)
-        h = self.attnblock(h, 'decoder.mid.attn_1', B, Hh, Ww); yield
-        h = yield from self.resblock(h, 'decoder.mid.block_2', B, Hh, Ww)
+        h = self.conv3(f_hat, 'post_quant_conv', B, Hh, Ww)
+        h = self.conv3(h, 'decoder.conv_in', B, Hh, Ww, stats=True)
+        h = self.resblock(h, 'decoder.mid.block_1', B, Hh, Ww)
+        h = self.attnblock(h, 'decoder.mid.attn_1', B, Hh, Ww)
+        h = self.resblock(h, 'decoder.mid.block_2', B, Hh, Ww)
         for lev in reversed(range(self.nlev)):
             for ib in range(3):
-                h = yield from self.resblock(h, f'decoder.up.{lev}.block.{ib}', B, Hh, Ww)
+                h = self.resblock(h, f'decoder.up.{lev}.block.{ib}', B, Hh, Ww)
                 if f'decoder.up.{lev}.attn.{ib}.norm.weight' in self.w:
-                    h = self.attnblock(h, f'decoder.up.{lev}.attn.{ib}', B, Hh, Ww); yield
+                    h = self.attnblock(h, f'decoder.up.{lev}.attn.{ib}', B, Hh, Ww)
             if lev != 0:                                             # Upsample2x: nearest 2x + conv3x3, as 4 phase convs on the low-res map
                 Hh, Ww = 2 * Hh, 2 * Ww
                 key = f'decoder.up.{lev}.upsample.conv'
@@ -388,68 +377,9 @@ class DecoderEngine(_VaeOps):
                     self._gn_part = (up, part, nblk)
                 else:
                     hip.call('upconv_phase_f32', h, wp, self.w[key + '.bias'], up, B, Hh, Ww, wp.shape[4], wp.shape[1])
-                h = up; yield
-        h = self.gn(h, 'decoder.norm_out', B, Hh * Ww, True); yield
+                h = up
+        h = self.gn(h, 'decoder.norm_out', B, Hh * Ww, True)
         return self.conv3(h, 'decoder.conv_out', B, Hh, Ww, out_mode=1 if denorm else 2)
-
-    overlap_halves = os.environ.get('VARHIP_DECODE_OVERLAP', '1') != '0'       # decode_nhwc: two halves of the batch on two streams, one step apart (False: one stream)
-
-    def _decode_two_streams(self, make_gen, f_hat: torch.Tensor) -> torch.Tensor:
-        """Run the decoder on the two halves of the batch, each on a stream of its own, the second half ONE STEP BEHIND the first: while
-        half A's conv (matrix-bound) runs, half B's GroupNorm apply (HBM-bound: 5-10 % of a decode as a pass of its own) shares the chip
-        with it instead of having it to itself, and vice versa.  Per-sample results do not depend on the split (every kernel of the
-        decoder treats samples independently)."""
-        B = f_hat.shape[0]
-        dev = f_hat.device
-        cur = torch.cuda.current_stream(dev)
-        if getattr(self, '_streams', None) is None or self._streams[0].device != dev:
-            self._streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
-        halves = (f_hat[:B // 2], f_hat[B // 2:])
-        gens, state, outs = [], [None, None], [None, None]
-        start = torch.cuda.Event(); start.record(cur)
-        for st in self._streams: st.wait_event(start)
-        for hf in halves: hf.record_stream(self._streams[0]); hf.record_stream(self._streams[1])
-        for i in (0, 1):
-            with torch.cuda.stream(self._streams[i]):
-                gens.append(make_gen(halves[i]))
-        # lockstep pipeline: in round t half A runs its step t beside half B's step t - 1, and nobody starts a step of round t + 1 before both
-        # have ended — so a half's conv only ever shares the chip with the other half's GroupNorm, never with its conv (per-kernel times and
-        # the roofline figures derived from them stay meaningful)
-        alive = [True, True]
-        ev_end = [None, None]                                        # end of each half's latest step
-        first = True
-        while alive[0] or alive[1]:
-            prev = list(ev_end)
-            for i in (0, 1):
-                if not alive[i] or (i == 1 and first): continue
-                st = self._streams[i]
-                other = prev[1 - i]
-                if other is not None: st.wait_event(other)
-                with torch.cuda.stream(st):
-                    self._gn_part = state[i]
-                    try: next(gens[i])
-                    except StopIteration as e: outs[i] = e.value; alive[i] = False
-                    state[i] = self._gn_part
-                    ev_end[i] = torch.cuda.Event(); ev_end[i].record(st)
-            first = False
-        self._gn_part = None
-        for i in (0, 1):
-            done = torch.cuda.Event(); done.record(self._streams[i]); cur.wait_event(done)
-            outs[i].record_stream(cur)
-        return torch.cat(outs, dim=0)
-
-    def decode_nhwc(self, f_hat: torch.Tensor, denorm: bool = True, precision: Optional[str] = None) -> torch.Tensor:
-        """[B,P,P,Cvae] channels-last -> [B,3,16P,16P]; denorm=True: in [0,1] (clamp and (x+1)/2 fused into the last conv, what
-        autoregressive_infer_cfg returns); denorm=False: clamped to [-1,1] (VQVAE.fhat_to_img's contract).
-        precision: 'f32' / 'f16' for THIS call (None: the engine's default, `self.precision`)"""
-        self.refresh()
-        f16 = (precision or self.precision) == 'f16'
-        if f16: self._ensure16()
-        make = (lambda x: self._decode16(x, denorm)) if f16 else (lambda x: self._decode32(x, denorm))
-        if self.overlap_halves and f_hat.shape[0] >= 2 and f_hat.is_cuda:
-            return self._decode_two_streams(make, f_hat)
-        self._gn_part = None
-        return self._drain(make(f_hat))
 
 
 class QuantizerEngine:
@@ -585,15 +515,15 @@ class EncoderEngine(DecoderEngine):
         h = self.conv3(x, 'encoder.conv_in', B, Hh, Ww)
         for lev in range(self.nlev):
             for ib in range(2):
-                h = self._drain(self.resblock(h, f'encoder.down.{lev}.block.{ib}', B, Hh, Ww))
+                h = self.resblock(h, f'encoder.down.{lev}.block.{ib}', B, Hh, Ww)
                 if f'encoder.down.{lev}.attn.{ib}.norm.weight' in self.w:
                     h = self.attnblock(h, f'encoder.down.{lev}.attn.{ib}', B, Hh, Ww)
             if lev != self.nlev - 1:
                 Hh, Ww = Hh // 2, Ww // 2
                 h = self.conv_s2(h, f'encoder.down.{lev}.downsample.conv', B, Hh, Ww)
-        h = self._drain(self.resblock(h, 'encoder.mid.block_1', B, Hh, Ww))
+        h = self.resblock(h, 'encoder.mid.block_1', B, Hh, Ww)
         h = self.attnblock(h, 'encoder.mid.attn_1', B, Hh, Ww)
-        h = self._drain(self.resblock(h, 'encoder.mid.block_2', B, Hh, Ww))
+        h = self.resblock(h, 'encoder.mid.block_2', B, Hh, Ww)
         h = self.conv3(self.gn(h, 'encoder.norm_out', B, Hh * Ww, True), 'encoder.conv_out', B, Hh, Ww)
         return self.conv3(h, 'quant_conv', B, Hh, Ww)
 
