@@ -718,7 +718,11 @@ extern "C" int varhip_gemm_nt_f16(const void* A, int64_t lda, const void* W, int
     p.M = M; p.N = N; p.K = K; p.epi = epi; p.rows_per_group = rows_per_group > 0 ? rows_per_group : 1; p.out_f16 = out_f16; p.resid_f16 = resid_f16;
     return run_gemm16(p, batch, (hipStream_t)stream, false, epi == VARHIP_EPI_RESID && !resid_f16,
                       2.0 * K + (out_f16 ? 2.0 : 4.0) * N, 2.0 * (double)N * K,
-                      [](Gemm16P& q, int pick, int b, hipStream_t s) { return pick == 0 ? launch16<4, 4>(q, b, s) : (g_gemm16_deep ? launch16<2, 2, 2, 2, 4>(q, b, s) : launch16<2, 2>(q, b, s)); });
+                      [](Gemm16P& q, int pick, int b, hipStream_t s) { if (pick == 0) return launch16<4, 4>(q, b, s);
+                          // fewer than one 64x64 tile per CU (the first scales: M = 128 .. 512 rows): 32x32 tiles, four times the workgroups, each streaming a
+                          // quarter of the bytes per K tile — such a launch is bound by what ONE CU can request per K tile, not by the chip
+                          if (g_gemm16_deep && (int64_t)((q.M + 63) / 64) * ((q.N + 63) / 64) * b < 256) return launch16<1, 1, 2, 2, 4>(q, b, s);
+                          return g_gemm16_deep ? launch16<2, 2, 2, 2, 4>(q, b, s) : launch16<2, 2>(q, b, s); });
 }
 
 // mat_qkv in the 16-bit mode: fp16 x fp16 -> fp32 accumulators -> (+bias, q/k L2 norm, scale) in fp32 -> fp16 q and fp16 KV-cache rows
@@ -735,5 +739,7 @@ extern "C" int varhip_gemm_qkv_f16(const void* A, int64_t lda, const void* W, in
     p.q_smul = scale_mul; p.q_out = (_Float16*)q_out; p.q_kc = (_Float16*)kcache; p.q_vc = (_Float16*)vcache; p.q_plain = plain_scale;
     p.q_l2 = l2norm; p.q_l = l; p.q_pos0 = pos0; p.q_Lmax = Lmax;
     return run_gemm16(p, 1, (hipStream_t)stream, true, false, 2.0 * K + 2.0 * 3.0 * C, 2.0 * 3.0 * C * (double)K,
-                      [](Gemm16P& q, int pick, int b, hipStream_t s) { return pick == 0 ? launch16<4, 4>(q, b, s) : (g_gemm16_deep ? launch16<2, 4, 2, 2, 3>(q, b, s) : launch16<2, 4>(q, b, s)); });
+                      [](Gemm16P& q, int pick, int b, hipStream_t s) { if (pick == 0) return launch16<4, 4>(q, b, s);
+                          if (g_gemm16_deep && (int64_t)((q.M + 63) / 64) * ((q.N + 127) / 128) < 256) return launch16<1, 4, 2, 2, 3>(q, b, s);      // 32 rows x one head per wave
+                          return g_gemm16_deep ? launch16<2, 4, 2, 2, 3>(q, b, s) : launch16<2, 4>(q, b, s); });
 }
