@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-step view of a rocprofv3 --kernel-trace CSV of bench.py: which kernels run INSIDE one sampling step, how often, for how long.
 
-  python tools/trace_steps.py <kernel_trace.csv> [--context NAME]
+  python tools/trace_steps.py <kernel_trace.csv> [--context NAME] [--head N]
 
 A step begins at `k_first_map` (the prologue kernel of SamplingEngine.sample, one launch per call).  Prints, for the last complete
 step, launches / total time per kernel name, and the same for everything BEFORE the first step (weight init, packing).  --context NAME:
@@ -40,6 +40,12 @@ def main(argv):
     gaps = sorted(((rows[i + 1][0] - rows[i][1]) for i in range(a, b - 1)), reverse=True)
     idle = sum(g for g in gaps if g > 0)
     print(f'== idle between kernels inside that step: {idle / 1e6:.3f} ms in total; ten largest gaps (us): {[round(g / 1e3, 1) for g in gaps[:10]]}')
+    if '--head' in argv:                                   # the first N launches of that step: duration and the idle gap in front of each
+        n = int(argv[argv.index('--head') + 1])
+        print(f'== first {n} launches of the step (us: duration, gap before)')
+        for i in range(a, min(a + n, b)):
+            gap = (rows[i][0] - rows[i - 1][1]) / 1e3 if i > a else 0.0
+            print(f'  {(rows[i][1] - rows[i][0]) / 1e3:8.1f} {gap:7.1f}  {rows[i][2].split("(")[0][:70]}')
     if ctx:
         hits = [i for i in range(a, b) if ctx in rows[i][2]][:12]
         for i in hits:

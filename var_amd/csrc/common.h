@@ -77,15 +77,35 @@ static inline int vh_launch_status() {
 }
 
 // ---- canonical reductions (CPU twins: canon_sum64 / canon_sum256 in oracle/var_oracle.c) -------------
-// every lane ends with the same value: p[j] + p[j^off] is commutative, so both partners compute identical bits
+// every lane ends with the same value: p[j] + p[j^off] is commutative, so both partners compute identical bits.
+// The butterfly partners lane ^ 32, ^ 16, ^ 8, ^ 4, ^ 2, ^ 1 are reached without the LDS crossbar (the compiler's __shfl_xor is a ds_bpermute: an
+// LDS round trip per step, six dependent ones per sum): the half / row swaps of gfx950 for 32 and 16 (permlaneNN_swap on two copies of v leaves
+// v in one result and the partner's v in the other: their sum / max is the step's result in both partners), DPP row operations for the rest
+// (row_ror:8 IS lane ^ 8 inside a row of 16; lane ^ 4 = row_shl:4 for lanes with bit 2 clear, row_shr:4 for the others; quad_perm for 2 and 1).
+// Same partners, same operand pairs as the shuffle form: bit-identical results (the LayerNorm / softmax / q-k-norm parity tests run on them).
+template <int CTRL> __device__ __forceinline__ float vh_mov_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float vh_lane_xor4(float v) {            // value of lane ^ 4
+    const float up = vh_mov_dpp<0x104>(v), dn = vh_mov_dpp<0x114>(v);      // row_shl:4 (from lane + 4), row_shr:4 (from lane - 4)
+    return (threadIdx.x & 4) ? dn : up;
+}
 __device__ __forceinline__ float vh_wave_sum(float p) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) p = p + __shfl_xor(p, off, 64);
+    { const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(p), __float_as_uint(p), false, false); p = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
+    { const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(p), __float_as_uint(p), false, false); p = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
+    p = p + vh_mov_dpp<0x128>(p);                                    // row_ror:8
+    p = p + vh_lane_xor4(p);
+    p = p + vh_mov_dpp<0x4E>(p);                                     // quad_perm [2,3,0,1]
+    p = p + vh_mov_dpp<0xB1>(p);                                     // quad_perm [1,0,3,2]
     return p;
 }
 __device__ __forceinline__ float vh_wave_max(float p) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) p = fmaxf(p, __shfl_xor(p, off, 64));
+    { const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(p), __float_as_uint(p), false, false); p = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1])); }
+    { const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(p), __float_as_uint(p), false, false); p = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1])); }
+    p = fmaxf(p, vh_mov_dpp<0x128>(p));
+    p = fmaxf(p, vh_lane_xor4(p));
+    p = fmaxf(p, vh_mov_dpp<0x4E>(p));
+    p = fmaxf(p, vh_mov_dpp<0xB1>(p));
     return p;
 }
 // 256-thread block: wave butterflies, then ((w0+w1)+w2)+w3.  `red` is >= 4 floats of LDS; contains a barrier pair.
