@@ -580,6 +580,11 @@ class SamplingEngine:
                     d[k + '16'] = d[k].to(torch.float16).contiguous()
             blocks.append(d)
         w['blocks'] = blocks
+        if not var.shared_aln and var.depth * 6 * C * C * 4 < 3.5e9:          # (beyond: the weight rows would leave the GEMM's 32-bit request offsets)
+            # all blocks' ada_lin projections as ONE GEMM per call (N = depth * 6C): sixteen launches of 192 workgroups each were bound by one
+            # workgroup's K loop (29 us each at d16); the packed copy (0.4 GB fp32 at d16) is rebuilt with the other copies when weights change
+            w['ada_w_all'] = torch.cat([d['ada_w'] for d in blocks], dim=0).contiguous()
+            w['ada_b_all'] = torch.cat([d['ada_b'] for d in blocks], dim=0).contiguous()
         if self.precision == 'f16':
             w['head_w16'] = w['head_w'].to(torch.float16).contiguous()
         w['codebook'] = g(quant.embedding.weight, 'codebook')
@@ -629,7 +634,7 @@ class SamplingEngine:
         act = torch.float16 if self.precision == 'f16' else torch.float32       # GEMM operands and KV cache; x / x2 / logits stay fp32
         ws = dict(dev=dev, x=e(M, C), x2=e(M, C), xn=e(M, C, dt=act), q=e(M, C, dt=act), att=e(M, C, dt=act), hid=e(M, hid, dt=act), logits=e(M, V),
                   idx=e(B * lmax, dt=torch.int64), lvl_pos=e(L, C), cond=e(2 * B, C), cond_silu=e(2 * B, C), hn=e(2 * B, 2 * C),
-                  ada=e(var.depth, 2 * B, 6 * C), shared=e(2 * B, 6 * C) if var.shared_aln else None,
+                  ada=e(var.depth, 2 * B, 6 * C) if var.shared_aln else e(2 * B, var.depth * 6 * C), shared=e(2 * B, 6 * C) if var.shared_aln else None,
                   kc=[torch.zeros(2 * B, H, L, 64, dtype=act, device=dev) for _ in range(var.depth)],
                   vc=[torch.zeros(2 * B, H, L, 64, dtype=act, device=dev) for _ in range(var.depth)],
                   f_hat=e(B, P, P, Cv), up=e(B, P, P, Cv), pooled=e(B * lmax, Cv))
@@ -659,12 +664,12 @@ class SamplingEngine:
         var = self.var
         C = var.C
         if self.precision == 'f16':
-            hip.call('adaln_block_f16', x, x2, ws['xn'], ws['q'], ws['att'], ws['hid'], ws['ada'][bi], 6 * C,
+            hip.call('adaln_block_f16', x, x2, ws['xn'], ws['q'], ws['att'], ws['hid'], ws['ada_view'][bi][0], ws['ada_view'][bi][1],
                      blk['qkv_w16'], blk['qkv_b'], blk['smul'], blk['plain_scale'], int(blk['l2']), blk['proj_w16'], blk['proj_b'],
                      blk['fc1_w16'], blk['fc1_b'], blk['fc2_w16'], blk['fc2_b'], ws['kc'][bi], ws['vc'][bi],
                      rows, l, C, var.num_heads, blk['fc1_w'].shape[0], cur, var.L, var.norm_eps)
             return
-        hip.call('adaln_block_f32', x, x2, ws['xn'], ws['q'], ws['att'], ws['hid'], ws['ada'][bi], 6 * C,
+        hip.call('adaln_block_f32', x, x2, ws['xn'], ws['q'], ws['att'], ws['hid'], ws['ada_view'][bi][0], ws['ada_view'][bi][1],
                  blk['qkv_w'], blk['qkv_b'], blk['smul'], blk['plain_scale'], int(blk['l2']), blk['proj_w'], blk['proj_b'],
                  blk['fc1_w'], blk['fc1_b'], blk['fc2_w'], blk['fc2_b'], ws['kc'][bi], ws['vc'][bi],
                  rows, l, C, var.num_heads, blk['fc1_w'].shape[0], cur, var.L, var.norm_eps)
@@ -761,11 +766,18 @@ class SamplingEngine:
         # AdaLN parameters of every block, once per call
         if var.shared_aln:
             self.gemm(ws['cond_silu'], w['sal_w'], w['sal_b'], ws['shared'], B2)
-        for bi, blk in enumerate(w['blocks']):
-            if var.shared_aln:
+        if var.shared_aln:
+            for bi, blk in enumerate(w['blocks']):
                 hip.call('add_bcast_f32', blk['gss'], ws['shared'], ws['ada'][bi], B2, 6 * C)
-            else:
-                self.gemm(ws['cond_silu'], blk['ada_w'], blk['ada_b'], ws['ada'][bi], B2)
+            ws['ada_view'] = [(ws['ada'][bi], 6 * C) for bi in range(var.depth)]
+        elif 'ada_w_all' in w:
+            self.gemm(ws['cond_silu'], w['ada_w_all'], w['ada_b_all'], ws['ada'], B2)          # row b: [block 0: 6C | block 1: 6C | ...]
+            ws['ada_view'] = [(ws['ada'][:, bi * 6 * C:], var.depth * 6 * C) for bi in range(var.depth)]
+        else:
+            ws['ada_view'] = [(ws['ada'][:, bi * 6 * C:], var.depth * 6 * C) for bi in range(var.depth)]
+            for bi, blk in enumerate(w['blocks']):
+                hip.call('gemm_nt_f32', ws['cond_silu'], C, blk['ada_w'], C, blk['ada_b'], ws['ada_view'][bi][0], var.depth * 6 * C, B2, 6 * C, C, EPI_NONE,
+                         None, 0, None, 0, 1, 0, 1, 0, 0, 0)
         self.gemm(ws['cond_silu'], w['hn_w'], w['hn_b'], ws['hn'], B2)
 
         x, x2 = ws['x'], ws['x2']
@@ -866,7 +878,7 @@ class SamplingEngine:
             M = R * lmax
             # x is written by first_map_f32 / word_embed_f32, which also emit the CFG copy of every row (unused here): room for 2x
             ws = dict(dev=dev, x=e(2 * M, C), x2=e(M, C), xn=e(M, C, dt=act), q=e(M, C, dt=act), att=e(M, C, dt=act), hid=e(M, hid, dt=act), lg=e(R * lmax, V),
-                      lvl_pos=e(L, C), cond=e(2 * R, C), cond_silu=e(2 * R, C), hn=e(R, 2 * C), ada=e(var.depth, R, 6 * C),
+                      lvl_pos=e(L, C), cond=e(2 * R, C), cond_silu=e(2 * R, C), hn=e(R, 2 * C), ada=e(var.depth, R, 6 * C) if var.shared_aln else e(R, var.depth * 6 * C),
                       shared=e(R, 6 * C) if var.shared_aln else None,
                       kc=[torch.zeros(R, H, L, 64, dtype=act, device=dev) for _ in range(var.depth)],
                       vc=[torch.zeros(R, H, L, 64, dtype=act, device=dev) for _ in range(var.depth)])
@@ -877,11 +889,18 @@ class SamplingEngine:
         hip.call('silu_f32', ws['cond'], ws['cond_silu'], R * C)
         if var.shared_aln:
             self.gemm(ws['cond_silu'], w['sal_w'], w['sal_b'], ws['shared'], R)
-        for bi, blk in enumerate(w['blocks']):
-            if var.shared_aln:
+        if var.shared_aln:
+            for bi, blk in enumerate(w['blocks']):
                 hip.call('add_bcast_f32', blk['gss'], ws['shared'], ws['ada'][bi], R, 6 * C)
-            else:
-                self.gemm(ws['cond_silu'], blk['ada_w'], blk['ada_b'], ws['ada'][bi], R)
+            ws['ada_view'] = [(ws['ada'][bi], 6 * C) for bi in range(var.depth)]
+        elif 'ada_w_all' in w:
+            self.gemm(ws['cond_silu'], w['ada_w_all'], w['ada_b_all'], ws['ada'], R)
+            ws['ada_view'] = [(ws['ada'][:, bi * 6 * C:], var.depth * 6 * C) for bi in range(var.depth)]
+        else:
+            ws['ada_view'] = [(ws['ada'][:, bi * 6 * C:], var.depth * 6 * C) for bi in range(var.depth)]
+            for bi, blk in enumerate(w['blocks']):
+                hip.call('gemm_nt_f32', ws['cond_silu'], C, blk['ada_w'], C, blk['ada_b'], ws['ada_view'][bi][0], var.depth * 6 * C, R, 6 * C, C, EPI_NONE,
+                         None, 0, None, 0, 1, 0, 1, 0, 0, 0)
         self.gemm(ws['cond_silu'], w['hn_w'], w['hn_b'], ws['hn'], R)
         out = torch.empty(R, L, V, dtype=torch.float32, device=dev)
         x, x2 = ws['x'], ws['x2']
