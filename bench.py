@@ -10,11 +10,13 @@ one all-gather of the decoded images inside the timed region (var_amd/multi.py).
 --dtype f32 (default, the driver's line): the parity mode — token ids bit-identical to the CPU oracle, priced against the 157.3 TF
 fp32 MFMA peak.  --dtype f16: the 16-bit throughput mode of the transformer (fp16 GEMM operands / KV cache, fp32 accumulation; what the
 reference's harness requests with torch.autocast(fp16), demo_sample.py:66-68), priced against the 2.5 PF dense fp16 MFMA peak.
+--dtype bf16: the same mode with bfloat16 storage (the reference's other 16-bit option, utils/arg_util.py `fp16: int  # 1: using fp16, 2: bf16`).
 
 Extra objects in the JSON line:
   modes.f16    (default run, after the f32 timed region, same process / weights / workload) the 16-bit throughput mode: 2 warmup + >= 10 timed
                steps between barriers, `value`, `ms_per_step`, its own measured dominant kernel with `roofline` and `whole_path`.  The
                headline `value` / `dtype` stay f32.
+  modes.bf16   the same for the bfloat16 flavour of that mode.
   ranks        (N > 1) each rank's own wall time per step, min and max over ranks, and the HIP-event time of the RCCL all-gather.
   roofline     the dominant kernel (largest device time among the single-symbol families, measured in the last warmup step with
                every family timed), re-timed alone with HIP events on the launch stream over the timed region: algorithmic FLOPs / time.
@@ -48,6 +50,7 @@ FAMILY_PEAK = {'gemm': PEAK_F32_MFMA_TFLOPS, 'gemm_small': PEAK_F32_MFMA_TFLOPS,
 # families: one template, 1-4 waves per workgroup by l)
 DOMINANT = {'f32': {'gemm': 'k_dma_gemm<4,4,false,2,false>', 'conv3x3': 'k_dma_gemm<4,5,true,2,false>', 'attn': 'k_attn_cached<NW>'},
             'f16': {'gemm16': 'k_gemm16p', 'conv16h': 'k_conv16h<5,32>', 'attn16': 'k_attn16<NW>'}}
+DOMINANT['bf16'] = DOMINANT['f16']          # the same kernels compiled with the bf16 MFMA opcodes (namespace vh_bf16 in the symbol)
 
 
 def run_mode(var, dtype, steps, warmup, args, world, step_fn, dist, hip, torch):
@@ -64,7 +67,7 @@ def run_mode(var, dtype, steps, warmup, args, world, step_fn, dist, hip, torch):
     if prepass is not None:
         dominant = max(fams, key=lambda k: prepass[k]['ms'])
     else:
-        dominant = {'f32': 'conv3x3' if args.depth <= 16 else 'gemm', 'f16': 'gemm16'}[dtype]          # (--warmup 0)
+        dominant = {'f32': 'conv3x3' if args.depth <= 16 else 'gemm', 'f16': 'gemm16', 'bf16': 'gemm16'}[dtype]          # (--warmup 0)
     hip.timing_reset(); hip.timing_enable(True, None if args.kernel_breakdown else [dominant])
     gather_ev = []
     dist.barrier(); torch.cuda.synchronize()
@@ -91,7 +94,7 @@ def run_mode(var, dtype, steps, warmup, args, world, step_fn, dist, hip, torch):
 def describe_mode(m, args, world, var, pns):
     """rank 0: the numbers of one precision mode as the JSON objects of the bench line"""
     dtype, dt, tt, prepass, dominant, steps = m['dtype'], m['dt'], m['tt'], m['prepass'], m['dominant'], m['steps']
-    f16 = dtype == 'f16'
+    f16 = dtype != 'f32'
     B_total = args.batch * world
     ips = B_total * steps / dt
     eng = var.engine()
@@ -103,7 +106,7 @@ def describe_mode(m, args, world, var, pns):
     kname = DOMINANT[dtype][dominant]
     peak = FAMILY_PEAK[dominant]
     traffic, tsrc = None, None                                   # HBM-side bytes per launch from a separate rocprofv3 --pmc pass of the same config
-    for prof in (f'r03_{dtype}_pmc_traffic.json', f'r02_{dtype}_pmc_traffic.json'):
+    for prof in () if dtype == 'bf16' else (f'r03_{dtype}_pmc_traffic.json', f'r02_{dtype}_pmc_traffic.json'):
         try:
             pj = json.load(open(os.path.join(ROOT, 'profiles', prof)))
             pm = pj['kernels'].get(kname)
@@ -150,8 +153,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--batch', type=int, default=64, help='images per GPU (weak scaling)')
     ap.add_argument('--depth', type=int, default=16)
-    ap.add_argument('--dtype', default='f32', choices=['f32', 'f16'], help='the mode of the headline value (default f32: the parity contract)')
-    ap.add_argument('--no-modes', action='store_true', help='skip the extra 16-bit-mode measurement that follows the f32 timed region (modes.f16)')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'f16', 'bf16'], help='the mode of the headline value (default f32: the parity contract)')
+    ap.add_argument('--no-modes', action='store_true', help='skip the extra 16-bit-mode measurements that follow the f32 timed region (modes.f16, modes.bf16)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--rng-mode', default='exact', choices=['exact', 'per_rank'])
     ap.add_argument('--host-init', action='store_true', help='generate the detinit weights with numpy on the host (same bits; keeps the ~8000 tiny init kernels out of a rocprofv3 counter pass)')
@@ -198,12 +201,14 @@ def main():
     head = run_mode(var, args.dtype, args.steps, args.warmup, args, world, step, dist, hip, torch)
     # then, in the same process, the 16-bit throughput mode (what the reference's harness runs under torch.autocast(fp16)): its own warmup,
     # >= 10 timed steps, its own dominant kernel and roofline.  The headline value / dtype stay those of the parity mode.
-    other = None
+    others = {}
     if args.dtype == 'f32' and not args.no_modes:
-        other = run_mode(var, 'f16', max(10, args.steps), 2, args, world, step, dist, hip, torch)
+        for dt16 in ('f16', 'bf16'):
+            others[dt16] = run_mode(var, dt16, max(10, args.steps), 2, args, world, step, dist, hip, torch)
 
     if rank == 0:
-        precision = {'f32': 'fp32 parity mode', 'f16': 'fp16 GEMM / conv operands, activations and KV cache, fp32 accumulate and statistics'}
+        precision = {'f32': 'fp32 parity mode', 'f16': 'fp16 GEMM / conv operands, activations and KV cache, fp32 accumulate and statistics',
+                     'bf16': 'bfloat16 GEMM / conv operands, activations and KV cache, fp32 accumulate and statistics'}
         var.set_hip_precision(args.dtype)
         ips, roof, whole, extra = describe_mode(head, args, world, var, pns)
         out = {
@@ -219,15 +224,15 @@ def main():
         }
         if head['ranks'] is not None:
             out['ranks'] = head['ranks']
-        if other is not None:
-            var.set_hip_precision('f16')
+        for dt16, other in others.items():
+            var.set_hip_precision(dt16)
             ips2, roof2, whole2, extra2 = describe_mode(other, args, world, var, pns)
-            out['modes'] = {'f16': {'value': round(ips2, 3), 'unit': 'images/sec', 'ms_per_step': round(other['dt'] / other['steps'] * 1e3, 3),
-                                    'steps': other['steps'], 'warmup': other['warmup'], 'dtype': 'f16', 'precision': precision['f16'],
-                                    'same_workload_as_headline': True, 'speedup_vs_headline': round(ips2 / ips, 3),
-                                    'roofline': roof2, 'whole_path': whole2, **extra2}}
+            out.setdefault('modes', {})[dt16] = {'value': round(ips2, 3), 'unit': 'images/sec', 'ms_per_step': round(other['dt'] / other['steps'] * 1e3, 3),
+                                                 'steps': other['steps'], 'warmup': other['warmup'], 'dtype': dt16, 'precision': precision[dt16],
+                                                 'same_workload_as_headline': True, 'speedup_vs_headline': round(ips2 / ips, 3),
+                                                 'roofline': roof2, 'whole_path': whole2, **extra2}
             if other['ranks'] is not None:
-                out['modes']['f16']['ranks'] = other['ranks']
+                out['modes'][dt16]['ranks'] = other['ranks']
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.depth, pns)
         print(json.dumps(out), flush=True)

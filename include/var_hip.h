@@ -316,6 +316,40 @@ int varhip_gn_apply_f16(const void* x, const float* stats, const float* gamma, c
 int varhip_cast_f32_to_f16(const float* in, void* out, int64_t n, varhip_stream_t stream);
 int varhip_cast_f16_to_f32(const void* in, float* out, int64_t n, varhip_stream_t stream);
 
+/* ---- the same mode with bfloat16 storage ("bf16"; the reference's other 16-bit option: utils/arg_util.py `fp16: int  # 1: using fp16, 2: bf16`,
+ * trainer / AmpOptimizer autocast dtype, utils/amp_sc.py).  One entry point per _f16 entry point above, same arguments and meaning with
+ * `void*` = bfloat16 data (the out_f16 / resid_f16 flags then mean bfloat16): the same kernels compiled with the bf16 MFMA opcodes and conversions
+ * (var_amd/csrc/elem16.h).  Rounding points as in the fp16 flavour; 8 significant bits instead of 11, fp32's exponent range. */
+int varhip_gemm_nt_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                       void* out, int64_t ldo, int out_f16, int M, int N, int K, int epi,
+                       const void* resid, int64_t ldr, int resid_f16, const float* gamma, int64_t ldg, int rows_per_group,
+                       int batch, int64_t sA, int64_t sW, int64_t sO, varhip_stream_t stream);
+int varhip_gemm16_force_tile(int tile);
+int varhip_gemm16_persistent(int on);
+int varhip_gemm_qkv_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, int M, int C, int K,
+                        const float* scale_mul, float plain_scale, int l2norm,
+                        void* q_out, void* kcache, void* vcache, int B2, int l, int H, int pos0, int Lmax, varhip_stream_t stream);
+int varhip_attn_cached_bf16(const void* q, const void* kcache, const void* vcache, void* out,
+                           int B2, int l, int H, int curL, int Lmax, varhip_stream_t stream);
+int varhip_ln_modulate_bf16out(const float* x, const float* scale, int64_t ld_scale, const float* shift, int64_t ld_shift,
+                              void* out, int M, int C, int rows_per_group, float eps, varhip_stream_t stream);
+int varhip_adaln_block_bf16(float* x, float* x2, void* xn16, void* q16, void* att16, void* hid16, const float* ada, int64_t ld_ada,
+                           const void* qkv_w16, const float* qkv_b, const float* scale_mul, float plain_scale, int l2norm,
+                           const void* proj_w16, const float* proj_b, const void* fc1_w16, const float* fc1_b,
+                           const void* fc2_w16, const float* fc2_b, void* kcache16, void* vcache16,
+                           int B2, int l, int C, int H, int hidden, int pos0, int Lmax, float eps, varhip_stream_t stream);
+int varhip_conv3x3_nhwc_bf16(const void* in, const void* w, const float* bias, const void* resid, void* out, double* gn_part,
+                            int B, int H, int W, int Cin, int Cout, int out_mode, varhip_stream_t stream);
+int varhip_upconv_phase_bf16(const void* in, const void* w_phase, const float* bias, void* out, double* gn_part,
+                            int B, int H, int W, int Cin, int Cout, varhip_stream_t stream);
+int varhip_conv16_force_tile(int wm);
+int varhip_gn_stats_bf16(const void* x, float* stats, double* scratch, int B, int HW, int C, int G, float eps, varhip_stream_t stream);
+int varhip_gn_apply_bf16(const void* x, const float* stats, const float* gamma, const float* beta, void* out,
+                        int B, int HW, int C, int G, int silu, varhip_stream_t stream);
+int varhip_cast_f32_to_bf16(const float* in, void* out, int64_t n, varhip_stream_t stream);
+int varhip_cast_bf16_to_f32(const void* in, float* out, int64_t n, varhip_stream_t stream);
+
+
 /* ---- per-kernel timing (bench.py's roofline leg) -----------------------------------------------------------
  * When enabled, every launch is bracketed by hipEvents on its own stream and its algorithmic FLOPs and bytes are
  * accumulated per kernel family.  varhip_timing_read synchronises the recorded events.

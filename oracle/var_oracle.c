@@ -302,8 +302,10 @@ int varref_attn_cached_f32(const float* q, const float* kcache, const float* vca
  * Plain ascending orders: this mode is compared with a tolerance, not bit for bit. */
 #include <immintrin.h>
 static inline float round_f16(float x) { return _cvtsh_ss(_cvtss_sh(x, _MM_FROUND_TO_NEAREST_INT)); }
-int varref_attn_cached_p16_f32(const float* q, const float* kcache, const float* vcache, float* out,
-                               int B2, int l, int H, int curL, int Lmax) {
+/* bfloat16 flavour of the same mode (include/var_hip.h "bf16"): round-to-nearest-even on the upper 16 bits of the fp32 pattern (finite inputs) */
+static inline float round_bf16(float x) { uint32_t u; memcpy(&u, &x, 4); u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u; memcpy(&x, &u, 4); return x; }
+static int attn_cached_p16(const float* q, const float* kcache, const float* vcache, float* out,
+                           int B2, int l, int H, int curL, int Lmax, int bf16) {
     if (curL <= 0 || curL > Lmax) return VARHIP_EINVAL;
     const int C = H * 64;
 #pragma omp parallel for collapse(2) schedule(dynamic, 4)
@@ -332,18 +334,25 @@ int varref_attn_cached_p16_f32(const float* q, const float* kcache, const float*
                     for (int jj = 0; jj < nj; ++jj) {
                         const float pj = vm_exp(s[jj] - m);
                         ls = ls + pj;
-                        const float p16 = round_f16(pj);
+                        const float p16 = bf16 ? round_bf16(pj) : round_f16(pj);
                         const float* vr = Vv + (int64_t)(j0 + jj) * 64;
 #pragma omp simd
                         for (int c = 0; c < 64; ++c) acc[c] = vm_fma(p16, vr[c], acc[c]);
                     }
                 }
                 float* o = out + ((int64_t)b * l + t) * C + h * 64;
-                for (int c = 0; c < 64; ++c) o[c] = round_f16(acc[c] / ls);
+                for (int c = 0; c < 64; ++c) o[c] = bf16 ? round_bf16(acc[c] / ls) : round_f16(acc[c] / ls);
             }
         }
     }
     return 0;
+}
+
+int varref_attn_cached_p16_f32(const float* q, const float* kcache, const float* vcache, float* out, int B2, int l, int H, int curL, int Lmax) {
+    return attn_cached_p16(q, kcache, vcache, out, B2, l, H, curL, Lmax, 0);
+}
+int varref_attn_cached_pbf16_f32(const float* q, const float* kcache, const float* vcache, float* out, int B2, int l, int H, int curL, int Lmax) {
+    return attn_cached_p16(q, kcache, vcache, out, B2, l, H, curL, Lmax, 1);
 }
 
 /* CFG (var.py:172-173) + sample_with_top_k_top_p_ (helpers.py:6-19) + torch.multinomial(n=1) == argmax(p / Exp(1) noise) */

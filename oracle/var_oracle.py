@@ -35,6 +35,10 @@ def lib():
         a16.argtypes = [abi.P, abi.P, abi.P, abi.P, abi.I, abi.I, abi.I, abi.I, abi.I]
         a16.restype = abi.I
         _LIB['attn_cached_p16_f32'] = a16
+        ab16 = so.varref_attn_cached_pbf16_f32       # ... and of its bfloat16 flavour
+        ab16.argtypes = list(a16.argtypes)
+        ab16.restype = abi.I
+        _LIB['attn_cached_pbf16_f32'] = ab16
     return _LIB
 
 
@@ -54,9 +58,14 @@ def f32(a) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
-def r16(a: np.ndarray) -> np.ndarray:
-    """round to fp16 (nearest-even) and back: the rounding points of the 16-bit throughput mode (include/var_hip.h, "f16")"""
-    return np.ascontiguousarray(a, dtype=np.float32).astype(np.float16).astype(np.float32)
+def r16(a: np.ndarray, kind: str = 'f16') -> np.ndarray:
+    """round to fp16 (kind='f16') or bfloat16 ('bf16'), nearest-even, and back: the rounding points of the 16-bit throughput mode
+    (include/var_hip.h, "f16" / "bf16")"""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if kind == 'bf16':                               # the upper 16 bits of the fp32 pattern (finite values)
+        u = a.view(np.uint32)
+        return ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)).view(np.float32)
+    return a.astype(np.float16).astype(np.float32)
 
 
 def _ck(rc, what):
@@ -102,11 +111,12 @@ class OracleVAR:
 
     def __init__(self, var_sd: Dict[str, np.ndarray], vae_sd: Dict[str, np.ndarray], patch_nums: Sequence[int], depth: int,
                  attn_l2_norm: bool = True, shared_aln: bool = False, num_classes: int = 1000, norm_eps: float = 1e-6,
-                 share_quant_resi: int = 4, quant_resi: float = 0.5, f16: bool = False):
-        """f16=True: the CPU twin of the 16-bit throughput mode — the same fp32 restatement with the rounding points of that mode
-        (fp16 block / head weights, LayerNorm output, q, k, v, attention probabilities and output, MLP hidden)."""
+                 share_quant_resi: int = 4, quant_resi: float = 0.5, f16=False):
+        """f16=True (or 'f16') / 'bf16': the CPU twin of the 16-bit throughput mode — the same fp32 restatement with the rounding points of
+        that mode (16-bit block / head weights, LayerNorm output, q, k, v, attention probabilities and output, MLP hidden) in that flavour."""
         self.L_ = lib()
         self.f16 = bool(f16)
+        self.kind16 = 'bf16' if f16 == 'bf16' else 'f16'
         self.sd = {k: (f32(v) if np.issubdtype(np.asarray(v).dtype, np.floating) else np.ascontiguousarray(v)) for k, v in var_sd.items()}
         self.vd = {k: f32(v) for k, v in vae_sd.items() if not k.startswith('encoder.') and not k.startswith('quant_conv.')}
         self.pns = tuple(patch_nums)
@@ -125,7 +135,7 @@ class OracleVAR:
         if key not in self._wt:
             w = self.sd[key] if w is None else w
             w = w.reshape(w.shape[0], -1)
-            self._wt[key] = np.ascontiguousarray((r16(w) if w16 else w).T)
+            self._wt[key] = np.ascontiguousarray((r16(w, self.kind16) if w16 else w).T)
         return self._wt[key]
 
     def linear(self, x, wkey, bias, epi=abi.EPI_NONE, resid=None, gamma=None, ldg=0, rows_per_group=1, w=None, w16=False):
@@ -194,7 +204,7 @@ class OracleVAR:
                 g1, g2, s1, s2, h1, h2 = (ada[:, i * C:(i + 1) * C] for i in range(6))
                 h16 = self.f16
                 hN = self.ln_mod(x, s1, h1, l)
-                if h16: hN = r16(hN)
+                if h16: hN = r16(hN, self.kind16)
                 bias_qkv = np.concatenate([sd[f'blocks.{b}.attn.q_bias'], np.zeros(C, np.float32), sd[f'blocks.{b}.attn.v_bias']]).astype(np.float32)
                 qkv = self.linear(hN, f'blocks.{b}.attn.mat_qkv.weight', bias_qkv, w16=h16)          # basic_var.py:93
                 q = np.empty((B2 * l, C), np.float32)
@@ -202,17 +212,18 @@ class OracleVAR:
                 _ck(Lf['qkv_prep_f32'](_p(qkv), _p(sm), 0.25 / 8.0, int(self.l2), _p(q), _p(kc[b]), _p(vc[b]), B2, l, H, cur, self.L), 'qkv_prep')
                 att = np.empty((B2 * l, C), np.float32)
                 if h16:            # fp16 q and fp16 cache rows; p rounded to fp16 for p.v, fp16 output
-                    q = r16(q)
-                    kc[b][:, :, cur:cur + l] = r16(kc[b][:, :, cur:cur + l]); vc[b][:, :, cur:cur + l] = r16(vc[b][:, :, cur:cur + l])
-                    _ck(Lf['attn_cached_p16_f32'](_p(q), _p(kc[b]), _p(vc[b]), _p(att), B2, l, H, cur + l, self.L), 'attn p16')
+                    k16 = self.kind16
+                    q = r16(q, k16)
+                    kc[b][:, :, cur:cur + l] = r16(kc[b][:, :, cur:cur + l], k16); vc[b][:, :, cur:cur + l] = r16(vc[b][:, :, cur:cur + l], k16)
+                    _ck(Lf['attn_cached_pbf16_f32' if k16 == 'bf16' else 'attn_cached_p16_f32'](_p(q), _p(kc[b]), _p(vc[b]), _p(att), B2, l, H, cur + l, self.L), 'attn p16')
                 else:
                     _ck(Lf['attn_cached_f32'](_p(q), _p(kc[b]), _p(vc[b]), _p(att), B2, l, H, cur + l, self.L), 'attn')
                 x = self.linear(att, f'blocks.{b}.attn.proj.weight', sd[f'blocks.{b}.attn.proj.bias'], abi.EPI_RESID, resid=x,
                                 gamma=g1, ldg=ada.shape[1], rows_per_group=l, w16=h16)                 # basic_var.py:157
                 hN = self.ln_mod(x, s2, h2, l)
-                if h16: hN = r16(hN)
+                if h16: hN = r16(hN, self.kind16)
                 hid = self.linear(hN, f'blocks.{b}.ffn.fc1.weight', sd[f'blocks.{b}.ffn.fc1.bias'], abi.EPI_GELU, w16=h16)
-                if h16: hid = r16(hid)
+                if h16: hid = r16(hid, self.kind16)
                 x = self.linear(hid, f'blocks.{b}.ffn.fc2.weight', sd[f'blocks.{b}.ffn.fc2.bias'], abi.EPI_RESID, resid=x,
                                 gamma=g2, ldg=ada.shape[1], rows_per_group=l, w16=h16)                 # basic_var.py:158
             cur += l
@@ -224,7 +235,7 @@ class OracleVAR:
                 # get_logits: AdaLNBeforeHead + head (var.py:118-124, basic_var.py:172-174)
                 hm = self.linear(cond_silu, 'head_nm.ada_lin.1.weight', sd['head_nm.ada_lin.1.bias'])
                 hN = self.ln_mod(x, hm[:, :C], hm[:, C:], l)
-                if self.f16: hN = r16(hN)
+                if self.f16: hN = r16(hN, self.kind16)
                 logits = self.linear(hN, 'head.weight', sd['head.bias'], w16=self.f16)
                 out['logits'].append(logits.reshape(B2, l, V))
                 idx = np.empty((B * l,), np.int64)

@@ -36,12 +36,13 @@ def test_bench_line_has_the_contract_keys():
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
     assert 'cpu_baseline' not in j and 'ranks' not in j
     # the 16-bit throughput mode, timed in the same process after the f32 region: its own value, steps, dominant kernel and roofline
-    m = j['modes']['f16']
-    assert m['dtype'] == 'f16' and m['steps'] >= 10 and m['warmup'] == 2 and m['value'] > 0 and m['unit'] == 'images/sec'
-    assert abs(m['value'] - 2 / (m['ms_per_step'] * 1e-3)) < 1e-2 * m['value'] and abs(m['speedup_vs_headline'] - m['value'] / j['value']) < 1e-2
-    r16 = m['roofline']
-    assert r16['peak'] == 2500.0 and r16['family'] in ('gemm16', 'conv16h', 'attn16') and 0 < r16['frac'] < 1 and r16['launches'] > 0
-    assert m['whole_path']['peak_tflops'] == 2500.0 and set(m['whole_path']['mfma_time_weighted']['families']) >= {'gemm16_small', 'gemm_small'}
+    for dt16 in ('f16', 'bf16'):
+        m = j['modes'][dt16]
+        assert m['dtype'] == dt16 and m['steps'] >= 10 and m['warmup'] == 2 and m['value'] > 0 and m['unit'] == 'images/sec'
+        assert abs(m['value'] - 2 / (m['ms_per_step'] * 1e-3)) < 1e-2 * m['value'] and abs(m['speedup_vs_headline'] - m['value'] / j['value']) < 1e-2
+        r16 = m['roofline']
+        assert r16['peak'] == 2500.0 and r16['family'] in ('gemm16', 'conv16h', 'attn16') and 0 < r16['frac'] < 1 and r16['launches'] > 0
+        assert m['whole_path']['peak_tflops'] == 2500.0 and set(m['whole_path']['mfma_time_weighted']['families']) >= {'gemm16_small', 'gemm_small'}
 
 
 def test_bench_line_f16_headline_and_no_modes():

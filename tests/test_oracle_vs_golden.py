@@ -281,3 +281,28 @@ def test_f16_twin_vs_reference_under_fp16_autocast(name):
     ok, m = util.diff_report(f'{name} image', r['img'], z['img'], atol=2e-2); ok_all &= ok; msgs.append(m)
     print('\n'.join(msgs))
     assert ok_all and agree >= 0.97, '\n'.join(msgs)
+
+
+@pytest.mark.parametrize('name', ['acbf16_t_pn12345', 'acbf16_d16_pn123'])
+def test_bf16_twin_vs_reference_under_bf16_autocast(name):
+    """The bfloat16 flavour of the twin (OracleVAR(f16='bf16')) against the reference under torch.autocast(dtype=bfloat16) (the reference's other
+    16-bit option, utils/arg_util.py `fp16: int  # 1: using fp16, 2: bf16`; tools/gen_golden.py run_case(autocast16='bf16')), teacher-forced.
+    bfloat16 keeps 8 significant bits: the reference's logits carry a bf16 rounding of their own (half an ulp = 3e-2 at |logit| 8..16) and every
+    activation one of 2^-9 relative, so the stated bars are 8x the fp16 ones: logits within 1.6e-2 x max|logit| (measured: 7e-3), token
+    agreement >= 95 % (measured 96-98 %), pixels within 1e-1 with mean <= 1e-2 (the reference's decoder runs its convs in bf16; measured 5e-2 / 5e-3)."""
+    z, meta = util.load_case(name)
+    assert meta['autocast16'] is True and meta['autocast_dtype'] == 'bf16'
+    var_sd, vae_sd = util.make_weights(meta)
+    twin = OracleVAR(var_sd, vae_sd, meta['patch_nums'], meta['depth'], attn_l2_norm=meta['attn_l2_norm'], shared_aln=meta['shared_aln'], f16='bf16')
+    r = twin.run(meta['labels'], util.regen_noise(meta, z), meta['cfg'], meta['top_k'], meta['top_p'], force_idx=z['idx'].astype(np.int64))
+    msgs, ok_all = [], True
+    for si, pn in enumerate(meta['patch_nums']):
+        lg, want = r['logits'][si], z[f'logits_s{si}']
+        got = lg if meta['full_logits'] else lg[:, sorted({0, pn * pn - 1}), :]
+        ok, m = util.diff_report(f'{name} bf16 twin logits s{si}', got, want, atol=1.6e-2 * max(float(np.abs(want).max()), 1.0)); ok_all &= ok; msgs.append(m)
+    agree = float((r['idx'] == z['idx']).mean())
+    msgs.append(f'{name}: bf16 twin tokens == reference-under-bf16-autocast tokens (teacher-forced): {agree:.3f}')
+    d = np.abs(r['img'] - z['img'])
+    msgs.append(f'{name}: image max |d| {float(d.max()):.3e} mean {float(d.mean()):.3e}')
+    print('\n'.join(msgs))
+    assert ok_all and agree >= 0.95 and float(d.max()) <= 1e-1 and float(d.mean()) <= 1e-2, '\n'.join(msgs)

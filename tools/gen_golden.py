@@ -76,6 +76,7 @@ def build_reference(cfg, init_seed=0):
 def run_case(name, cfg, autocast16=False):
     """autocast16: the reference's own 16-bit execution — the call wrapped in torch.autocast(dtype=float16) exactly as demo_sample.py:66-68 does
     (device 'cpu' here: F.linear / conv2d / SDPA run on fp16 operands with fp16 results, LayerNorm / softmax / get_logits' .float() in fp32).
+    autocast16='bf16': the same under torch.autocast(dtype=bfloat16), the reference's other 16-bit option (utils/arg_util.py `fp16: int  # 1: using fp16, 2: bf16`).
     These fixtures pin the 16-bit throughput mode (and its CPU twin) against the reference itself, with a tolerance."""
     vae, var = build_reference(cfg)
     pns = tuple(cfg['patch_nums'])
@@ -102,7 +103,7 @@ def run_case(name, cfg, autocast16=False):
 
     t0 = time.time()
     import contextlib
-    with torch.inference_mode(), (torch.autocast('cpu', dtype=torch.float16) if autocast16 else contextlib.nullcontext()):
+    with torch.inference_mode(), (torch.autocast('cpu', dtype=torch.bfloat16 if autocast16 == 'bf16' else torch.float16) if autocast16 else contextlib.nullcontext()):
         img = var.autoregressive_infer_cfg(B, torch.tensor(cfg['labels'], dtype=torch.long), g_seed=cfg['seed'], cfg=cfg['cfg'],
                                            top_k=cfg['top_k'], top_p=cfg['top_p'], more_smooth=False)
     dt = time.time() - t0
@@ -131,6 +132,7 @@ def run_case(name, cfg, autocast16=False):
     meta = dict(cfg); meta['B'] = B; meta['V'] = int(V); meta['ref_seconds'] = dt; meta['torch'] = torch.__version__
     meta['threads'] = torch.get_num_threads()
     meta['autocast16'] = bool(autocast16)
+    meta['autocast_dtype'] = ('bf16' if autocast16 == 'bf16' else 'f16') if autocast16 else None
     rec['meta'] = np.array(json.dumps(meta))
     np.savez_compressed(os.path.join(GOLD, f'e2e_{name}.npz'), **rec)
     print(f'[gen_golden] {name}: {dt:.2f}s  img mean {img.mean():.4f}  tokens {rec["idx"].shape}', flush=True)
@@ -386,6 +388,8 @@ def main():
         run_case(name, cfg)
     for base in ('t_pn12345', 't_saln', 'd16_pn123'):                 # the reference under its harness' fp16 autocast (demo_sample.py:66-68)
         if not args.only or ('ac16_' + base) in args.only: run_case('ac16_' + base, CASES[base], autocast16=True)
+    for base in ('t_pn12345', 'd16_pn123'):                           # ... and under bfloat16 autocast
+        if not args.only or ('acbf16_' + base) in args.only: run_case('acbf16_' + base, CASES[base], autocast16='bf16')
     if not args.only or 'inpaint' in args.only: run_inpaint()
     if not args.only or 'more_smooth' in args.only: run_more_smooth()
     if not args.only or 'inpaint_more_smooth' in args.only: run_inpaint_more_smooth()

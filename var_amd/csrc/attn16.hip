@@ -11,11 +11,14 @@
 // second product by pairwise conversion to fp16 (registers 8s .. 8s+7 = the fragment of step s); the V^T fragment of that step is stored
 // in LDS in the matching key order (cdna_hip_programming.md §3, "an accumulator tile as the next MFMA's operand").
 #include "common.h"
+#include "elem16.h"
 
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-typedef __fp16 vf4 __attribute__((__vector_size__(4 * sizeof(__fp16))));      // the transposing LDS read's result type
+namespace VH16_NS {
+
+typedef vh_e16 h8 __attribute__((ext_vector_type(8)));
+typedef vh_e16 h4 __attribute__((ext_vector_type(4)));
+typedef vh_e16 h2 __attribute__((ext_vector_type(2)));
+typedef short vs4 __attribute__((ext_vector_type(4)));                       // the transposing LDS read's result: four 16-bit elements, whatever their type
 
 #define OLD16 72          // halves per row of the output staging tile (64 + 8 pad)
 
@@ -25,8 +28,8 @@ __device__ __forceinline__ void vh16a_dma16(const void* base, uint32_t voff, uin
 __device__ __forceinline__ float vh16a_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 
 template <int NW>
-__global__ void __launch_bounds__(NW * 64, NW) k_attn16(const _Float16* __restrict__ q, const _Float16* __restrict__ kcache, const _Float16* __restrict__ vcache,
-                                                         _Float16* __restrict__ out, int l, int H, int curL, int Lmax) {
+__global__ void __launch_bounds__(NW * 64, NW) k_attn16(const vh_e16* __restrict__ q, const vh_e16* __restrict__ kcache, const vh_e16* __restrict__ vcache,
+                                                         vh_e16* __restrict__ out, int l, int H, int curL, int Lmax) {
     constexpr int NT = NW * 64, NIT = (256 + NT - 1) / NT;
     constexpr int KST = 32 * 128, VST = 32 * 128;                 // bytes per K / V stage (32 keys x 64 halves)
     constexpr int OST = NW * 32 * OLD16 * 2;                      // bytes of the output staging tile (reuses the K / V stages)
@@ -39,15 +42,15 @@ __global__ void __launch_bounds__(NW * 64, NW) k_attn16(const _Float16* __restri
     const int b = blockIdx.z, hd = blockIdx.y;
     const int C = H * 64;
     const int t0 = (blockIdx.x * NW + wave) * 32;
-    const _Float16* Kc = kcache + ((int64_t)b * H + hd) * Lmax * 64;
-    const _Float16* Vc = vcache + ((int64_t)b * H + hd) * Lmax * 64;
+    const vh_e16* Kc = kcache + ((int64_t)b * H + hd) * Lmax * 64;
+    const vh_e16* Vc = vcache + ((int64_t)b * H + hd) * Lmax * 64;
     const int ntile = (curL + 31) / 32;
 
     // Q fragments: lane (query r, half h), step t: q[16t + 8h .. + 7]
     h8 qf[4];
     {
         const int t = t0 + r;
-        const _Float16* src = q + ((int64_t)b * l + (t < l ? t : 0)) * C + hd * 64 + h2 * 8;
+        const vh_e16* src = q + ((int64_t)b * l + (t < l ? t : 0)) * C + hd * 64 + h2 * 8;
 #pragma unroll
         for (int s = 0; s < 4; ++s) qf[s] = *(const h8*)(src + s * 16);
     }
@@ -105,11 +108,11 @@ __global__ void __launch_bounds__(NW * 64, NW) k_attn16(const _Float16* __restri
             {
                 const char* kb = sK + buf * KST + r * 128;
                 h8 kf = *(const h8*)(kb + (((0 + h2) ^ kxor) << 4));
-                p = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[0], (f32x16)(0.f), 0, 0, 0);
+                p = VH16_MFMA_32x32x16(kf, qf[0], (f32x16)(0.f));
 #pragma unroll
                 for (int s = 1; s < 4; ++s) {
                     kf = *(const h8*)(kb + (((2 * s + h2) ^ kxor) << 4));
-                    p = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], p, 0, 0, 0);
+                    p = VH16_MFMA_32x32x16(kf, qf[s], p);
                 }
             }
             const bool ragged = kt * 32 + 32 > curL;
@@ -144,19 +147,18 @@ __global__ void __launch_bounds__(NW * 64, NW) k_attn16(const _Float16* __restri
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pf[s][j] = (_Float16)p[8 * s + j];
+                for (int j = 0; j < 8; ++j) pf[s][j] = (vh_e16)p[8 * s + j];
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 // V^T fragments of step s: elements 0..3 = keys 16s + 4h + 0..3, elements 4..7 = keys 16s + 8 + 4h + 0..3 (the order of pf)
-                h8 v0, v1;
-                const vf4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) vf4*)v_addr(buf, s, 0, 0));
-                const vf4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) vf4*)v_addr(buf, s, 1, 0));
-                const vf4 c0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) vf4*)v_addr(buf, s, 0, 1));
-                const vf4 c1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) vf4*)v_addr(buf, s, 1, 1));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v0[e] = (_Float16)a0[e]; v0[4 + e] = (_Float16)a1[e]; v1[e] = (_Float16)c0[e]; v1[4 + e] = (_Float16)c1[e]; }
-                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, pf[s], o0, 0, 0, 0);      // channels r
-                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, pf[s], o1, 0, 0, 0);      // channels r + 32
+                const vs4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) vs4*)v_addr(buf, s, 0, 0));
+                const vs4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) vs4*)v_addr(buf, s, 1, 0));
+                const vs4 c0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) vs4*)v_addr(buf, s, 0, 1));
+                const vs4 c1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) vs4*)v_addr(buf, s, 1, 1));
+                const h8 v0 = __builtin_shufflevector(__builtin_bit_cast(h4, a0), __builtin_bit_cast(h4, a1), 0, 1, 2, 3, 4, 5, 6, 7);
+                const h8 v1 = __builtin_shufflevector(__builtin_bit_cast(h4, c0), __builtin_bit_cast(h4, c1), 0, 1, 2, 3, 4, 5, 6, 7);
+                o0 = VH16_MFMA_32x32x16(v0, pf[s], o0);      // channels r
+                o1 = VH16_MFMA_32x32x16(v1, pf[s], o1);      // channels r + 32
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -169,12 +171,12 @@ __global__ void __launch_bounds__(NW * 64, NW) k_attn16(const _Float16* __restri
     }
     // O^T accumulators: col (lane & 31) = query, row = channel.  fp16, transposed through LDS, stored as 128-byte rows (16 B per lane).
     {
-        _Float16* st = (_Float16*)smem + wave * 32 * OLD16;
+        vh_e16* st = (vh_e16*)smem + wave * 32 * OLD16;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             h4 a, c;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { a[e] = (_Float16)(o0[4 * g + e] * inv); c[e] = (_Float16)(o1[4 * g + e] * inv); }
+            for (int e = 0; e < 4; ++e) { a[e] = (vh_e16)(o0[4 * g + e] * inv); c[e] = (vh_e16)(o1[4 * g + e] * inv); }
             *(h4*)(st + r * OLD16 + 8 * g + 4 * h2) = a;               // channels 8g + 4h .. + 3
             *(h4*)(st + r * OLD16 + 32 + 8 * g + 4 * h2) = c;
         }
@@ -195,7 +197,7 @@ static int attn16_waves(int l) {
     return best;
 }
 
-extern "C" int varhip_attn_cached_f16(const void* q, const void* kcache, const void* vcache, void* out,
+extern "C" int VH16_FN(attn_cached)(const void* q, const void* kcache, const void* vcache, void* out,
                                       int B2, int l, int H, int curL, int Lmax, varhip_stream_t stream) {
     if (B2 <= 0 || l <= 0 || H <= 0 || curL <= 0 || curL > Lmax) return VARHIP_EINVAL;
     if (B2 > 65535 || H > 65535 || (((uintptr_t)q | (uintptr_t)kcache | (uintptr_t)vcache | (uintptr_t)out) & 15)) return VARHIP_EINVAL;
@@ -203,8 +205,8 @@ extern "C" int varhip_attn_cached_f16(const void* q, const void* kcache, const v
     const int nw = attn16_waves(l);
     dim3 grid((l + nw * 32 - 1) / (nw * 32), H, B2);
     hipStream_t s = (hipStream_t)stream;
-    const _Float16 *q_ = (const _Float16*)q, *k_ = (const _Float16*)kcache, *v_ = (const _Float16*)vcache;
-    _Float16* o_ = (_Float16*)out;
+    const vh_e16 *q_ = (const vh_e16*)q, *k_ = (const vh_e16*)kcache, *v_ = (const vh_e16*)vcache;
+    vh_e16* o_ = (vh_e16*)out;
     switch (nw) {
         case 1: hipLaunchKernelGGL((k_attn16<1>), grid, dim3(64), 0, s, q_, k_, v_, o_, l, H, curL, Lmax); break;
         case 2: hipLaunchKernelGGL((k_attn16<2>), grid, dim3(128), 0, s, q_, k_, v_, o_, l, H, curL, Lmax); break;
@@ -213,3 +215,5 @@ extern "C" int varhip_attn_cached_f16(const void* q, const void* kcache, const v
     }
     return vh_launch_status();
 }
+
+}  // namespace VH16_NS

@@ -10,12 +10,15 @@
 // k-step, so the LDS pipeline is NST stages deep with counted s_waitcnt vmcnt (a tile's 20 MFMAs per wave are over in ~320 cycles,
 // far less than one memory latency).  LDS rows of 64 bytes: slot c of row r holds chunk c ^ ((-(r >> 2)) & 3) (conflict-free b128 reads).
 #include "common.h"
+#include "elem16.h"
 
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+namespace VH16_NS {
+
+typedef vh_e16 h8 __attribute__((ext_vector_type(8)));
+typedef vh_e16 h4 __attribute__((ext_vector_type(4)));
 
 struct Conv16P {
-    const _Float16* in; const _Float16* w; const float* bias; void* out; const _Float16* resid; double* gn_part;
+    const vh_e16* in; const vh_e16* w; const float* bias; void* out; const vh_e16* resid; double* gn_part;
     int M, N, K;                   // pixels (of the low-res map in the phase mode), Cout, taps * Cin
     int H, Wd, Cin, phase, out_mode;     // H, Wd: the map the M pixels live on; phase: Upsample2x phase form (grid.z = 4 phases)
     int64_t sW;                    // element stride between the phase weight sets
@@ -62,7 +65,7 @@ __global__ void __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(W
     }
     const int m0 = tm_ * BM, n0 = tn_ * BN, bz = blockIdx.z;
     const int hw = p.H * p.Wd, ntap = p.phase ? 4 : 9;
-    const _Float16* Wb = p.w + (int64_t)bz * p.sW;
+    const vh_e16* Wb = p.w + (int64_t)bz * p.sW;
 
     // input window of this workgroup's buffer descriptor: from one row + one pixel before the first sample the tile touches
     const int mlast = (m0 + BM - 1 < p.M ? m0 + BM - 1 : p.M - 1), mfirst = m0 < p.M ? m0 : p.M - 1;
@@ -144,7 +147,7 @@ __global__ void __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(W
 #pragma unroll
             for (int i = 0; i < TMW; ++i)
 #pragma unroll
-                for (int j = 0; j < TNW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bn[j], am[i], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TNW; ++j) acc[i][j] = VH16_MFMA_16x16x32(bn[j], am[i], acc[i][j]);
         }
     }
     __syncthreads();                                              // the stages are free: the GroupNorm partials below reuse them
@@ -200,8 +203,8 @@ __global__ void __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(W
                                for (int e = 0; e < 4; ++e) v[e] = (float)r4[e] + v[e]; }
                 h4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
-                *(h4*)((_Float16*)p.out + (int64_t)(p.phase ? mo_ph : m) * p.N + n) = o;
+                for (int e = 0; e < 4; ++e) o[e] = (vh_e16)v[e];
+                *(h4*)((vh_e16*)p.out + (int64_t)(p.phase ? mo_ph : m) * p.N + n) = o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { const float d = (float)o[e]; gs[e] += d; gq[e] += d * d; }     // statistics of what the next GroupNorm will read: the rounded values
             }
@@ -246,7 +249,7 @@ __global__ void __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(W
                     if (n + e >= p.N) break;
                     float x = v[e];
                     if (p.resid) x = (float)p.resid[(int64_t)m * p.N + n + e] + x;
-                    ((_Float16*)p.out)[mo * p.N + n + e] = (_Float16)x;
+                    ((vh_e16*)p.out)[mo * p.N + n + e] = (vh_e16)x;
                 }
             }
         }
@@ -366,7 +369,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
 #pragma unroll
             for (int i = 0; i < TMW; ++i) {
 #pragma unroll
-                for (int j = 0; j < TNW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bn[j], am[i & 1], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TNW; ++j) acc[i][j] = VH16_MFMA_16x16x32(bn[j], am[i & 1], acc[i][j]);
                 __builtin_amdgcn_sched_barrier(0);
                 if (i + 2 < TMW) am[i & 1] = lda(i + 2);
             }
@@ -412,8 +415,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
                            for (int e = 0; e < 4; ++e) v[e] = (float)r4[e] + v[e]; }
             h4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
-            *(h4*)((_Float16*)p.out + m * p.N + n) = o;
+            for (int e = 0; e < 4; ++e) o[e] = (vh_e16)v[e];
+            *(h4*)((vh_e16*)p.out + m * p.N + n) = o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const float d = (float)o[e]; gs[e] += d; gq[e] += d * d; }
         }
@@ -465,22 +468,20 @@ static int launch_conv16(Conv16P& p, int nz, hipStream_t s) {
     hipLaunchKernelGGL(kfn, dim3(p.tilesM * p.tilesN, 1, nz), dim3(WM * 128), lds, s, p);
     return vh_launch_status();
 }
-static int g_conv16_force_wm = 0;                                 // 0: by size; 2 / 4: experiments (tools/bench_kernels.py, tests)
-extern "C" int varhip_conv16_force_tile(int wm) { g_conv16_force_wm = (wm == 2 || wm == 4 || wm == 8) ? wm : 0; return 0; }
 // which kernel takes a launch: 1 / 2 = the halo-patch kernel with 8x32 / 16x16 patches, 3 = 256-pixel tiles, 0 = 128-pixel tiles
 static int pick_conv16(const Conv16P& p, int nz) {
     // the halo-patch kernel: plain 3x3 convs on maps that tile into 8x32 or 16x16 patches, once there is a workgroup for every CU
-    if (!p.phase && p.out_mode == 0 && g_conv16_force_wm != 2 && g_conv16_force_wm != 4 && (p.N % 160 == 0 || p.N % 128 == 0)
+    if (!p.phase && p.out_mode == 0 && vh_g_conv16_force_wm != 2 && vh_g_conv16_force_wm != 4 && (p.N % 160 == 0 || p.N % 128 == 0)
         && (int64_t)p.H * p.Wd * p.Cin * 2 < (1ll << 31)
-        && (g_conv16_force_wm == 8 || (int64_t)(p.M / 256) * (p.N / (p.N % 160 == 0 ? 160 : 128)) >= 256)) {
+        && (vh_g_conv16_force_wm == 8 || (int64_t)(p.M / 256) * (p.N / (p.N % 160 == 0 ? 160 : 128)) >= 256)) {
         const int64_t wgs = (int64_t)(p.M / 256) * (p.N / (p.N % 160 == 0 ? 160 : 128));
-        const bool w32 = (p.Wd % 32 == 0) && (p.H % 8 == 0), w16 = (p.Wd % 16 == 0) && (p.H % 16 == 0) && (g_conv16_force_wm == 8 || wgs >= 512);
+        const bool w32 = (p.Wd % 32 == 0) && (p.H % 8 == 0), w16 = (p.Wd % 16 == 0) && (p.H % 16 == 0) && (vh_g_conv16_force_wm == 8 || wgs >= 512);
         if (w32) return 1;
         if (w16) return 2;
     }
     // 256-pixel tiles (8 waves, two workgroups per CU) once they give every CU a workgroup
     const int64_t big_wgs = (int64_t)((p.M + 255) / 256) * ((p.N + 159) / 160) * nz;
-    return (g_conv16_force_wm ? g_conv16_force_wm == 4 : big_wgs >= 256) ? 3 : 0;
+    return (vh_g_conv16_force_wm ? vh_g_conv16_force_wm == 4 : big_wgs >= 256) ? 3 : 0;
 }
 // timing family of a launch: k_conv16h<5,32> (the decoder's dominant symbol) alone in VH_FAM_CONV16H
 static int conv16_family(const Conv16P& p, int nz) { return (pick_conv16(p, nz) == 1 && p.N % 160 == 0) ? VH_FAM_CONV16H : VH_FAM_CONV16_SMALL; }
@@ -504,7 +505,7 @@ static int conv16_checks(const void* in, const void* w, const float* bias, const
 
 // out = conv3x3(in) + bias (+ resid): in [B][H][W][Cin] fp16, w [Cout][3][3][Cin] fp16, bias fp32, resid / out [B][H][W][Cout] fp16
 // out_mode 1 / 2: the decoder's last conv — fp32 NCHW, clamped to [-1, 1] (2) or de-normalised to [0, 1] (1); gn_part as in gemm.hip
-extern "C" int varhip_conv3x3_nhwc_f16(const void* in, const void* w, const float* bias, const void* resid, void* out, double* gn_part,
+extern "C" int VH16_FN(conv3x3_nhwc)(const void* in, const void* w, const float* bias, const void* resid, void* out, double* gn_part,
                                        int B, int H, int W, int Cin, int Cout, int out_mode, varhip_stream_t stream) {
     int rc = conv16_checks(in, w, bias, out, B, H, W, Cin, Cout);
     if (rc) return rc;
@@ -514,7 +515,7 @@ extern "C" int varhip_conv3x3_nhwc_f16(const void* in, const void* w, const floa
     {   const int64_t hw = (int64_t)H * W, sample = hw * Cin;
         if (((255 / hw + 2) * sample + (int64_t)(W + 1) * Cin) * 2 >= (1ll << 31)) return VARHIP_EINVAL; }
     Conv16P p{};
-    p.in = (const _Float16*)in; p.w = (const _Float16*)w; p.bias = bias; p.out = out; p.resid = (const _Float16*)resid; p.gn_part = gn_part;
+    p.in = (const vh_e16*)in; p.w = (const vh_e16*)w; p.bias = bias; p.out = out; p.resid = (const vh_e16*)resid; p.gn_part = gn_part;
     p.M = B * H * W; p.N = Cout; p.K = 9 * Cin; p.H = H; p.Wd = W; p.Cin = Cin; p.phase = 0; p.out_mode = out_mode; p.sW = 0;
     const double npix = (double)B * H * W;
     VhScope scope(conv16_family(p, 1), (hipStream_t)stream, 2.0 * npix * Cout * 9.0 * Cin,
@@ -524,7 +525,7 @@ extern "C" int varhip_conv3x3_nhwc_f16(const void* in, const void* w, const floa
 
 // nearest-2x upsample + conv3x3 as four 2x2 phase convolutions on the low-resolution map: in [B][H/2][W/2][Cin] fp16,
 // w_phase [4][Cout][2][2][Cin] fp16 (varhip_upconv_pack_f32, then rounded to fp16), out [B][H][W][Cout] fp16
-extern "C" int varhip_upconv_phase_f16(const void* in, const void* w_phase, const float* bias, void* out, double* gn_part,
+extern "C" int VH16_FN(upconv_phase)(const void* in, const void* w_phase, const float* bias, void* out, double* gn_part,
                                        int B, int H, int W, int Cin, int Cout, varhip_stream_t stream) {
     int rc = conv16_checks(in, w_phase, bias, out, B, H, W, Cin, Cout);
     if (rc) return rc;
@@ -533,7 +534,7 @@ extern "C" int varhip_upconv_phase_f16(const void* in, const void* w_phase, cons
     {   const int64_t hw = (int64_t)(H / 2) * (W / 2), sample = hw * Cin;
         if (((255 / hw + 2) * sample + (int64_t)(W / 2 + 1) * Cin) * 2 >= (1ll << 31)) return VARHIP_EINVAL; }
     Conv16P p{};
-    p.in = (const _Float16*)in; p.w = (const _Float16*)w_phase; p.bias = bias; p.out = out; p.resid = nullptr; p.gn_part = gn_part;
+    p.in = (const vh_e16*)in; p.w = (const vh_e16*)w_phase; p.bias = bias; p.out = out; p.resid = nullptr; p.gn_part = gn_part;
     p.M = B * (H / 2) * (W / 2); p.N = Cout; p.K = 4 * Cin; p.H = H / 2; p.Wd = W / 2; p.Cin = Cin; p.phase = 1; p.out_mode = 0;
     p.sW = (int64_t)Cout * 4 * Cin;
     const double npix = (double)B * H * W;
@@ -541,3 +542,5 @@ extern "C" int varhip_upconv_phase_f16(const void* in, const void* w_phase, cons
                   2.0 * (npix * Cin / 4.0 + npix * Cout + 16.0 * Cin * Cout));
     return dispatch_conv16(p, 4, (hipStream_t)stream);
 }
+
+}  // namespace VH16_NS

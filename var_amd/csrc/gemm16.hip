@@ -13,12 +13,15 @@
 // fragment of a 16x16x32 step is 8 consecutive k = one 16-byte chunk: one ds_read_b128 per 16-row fragment and step
 // (conflict-free with that swizzle), two steps per K tile.
 #include "common.h"
+#include "elem16.h"
 
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+namespace VH16_NS {
+
+typedef vh_e16 h8 __attribute__((ext_vector_type(8)));
+typedef vh_e16 h4 __attribute__((ext_vector_type(4)));
 
 struct Gemm16P {
-    const _Float16* A; const _Float16* W; const float* bias; void* out; const void* resid; const float* gamma;
+    const vh_e16* A; const vh_e16* W; const float* bias; void* out; const void* resid; const float* gamma;
     int64_t lda, ldw, ldo, ldr, ldg, sA, sW, sO;
     int M, N, K, epi, rows_per_group, out_f16, resid_f16;
     int m_base;                // rows of the GEMM in front of this launch (a GEMM may be issued as two launches over row ranges): A / out / resid are pre-offset, gamma's row
@@ -26,7 +29,7 @@ struct Gemm16P {
     int tilesM, tilesN;
     int dbg;                   // experiments (k_gemm16p): bit 0 no global stores, bit 1 no epilogue, bits 8.. stagger (odd workgroups sleep dbg >> 8 x 8k cycles first)
     // epi == 3: fused q/k/v epilogue (N = 3C, head_dim 64)
-    const float* q_smul; _Float16* q_out; _Float16* q_kc; _Float16* q_vc; float q_plain; int q_l2, q_l, q_pos0, q_Lmax;
+    const float* q_smul; vh_e16* q_out; vh_e16* q_kc; vh_e16* q_vc; float q_plain; int q_l2, q_l, q_pos0, q_Lmax;
 };
 
 template <int N> __device__ __forceinline__ void vh16_waitcnt_barrier() { asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory"); }
@@ -151,7 +154,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) k_gemm16(Gemm16P p) {
 #pragma unroll
                 for (int i = 0; i < TMW; ++i)
 #pragma unroll
-                    for (int j = 0; j < TNW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bn[s][j], am[s][i], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TNW; ++j) acc[i][j] = VH16_MFMA_16x16x32(bn[s][j], am[s][i], acc[i][j]);
                 if (s == 0) mid();
             }
         } else {
@@ -172,7 +175,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) k_gemm16(Gemm16P p) {
 #pragma unroll
                 for (int i = 0; i < TMW; ++i)
 #pragma unroll
-                    for (int j = 0; j < TNW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bn[s][j], am[i], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TNW; ++j) acc[i][j] = VH16_MFMA_16x16x32(bn[s][j], am[i], acc[i][j]);
                 if (s == 0) mid();
             }
         }
@@ -265,22 +268,22 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) k_gemm16(Gemm16P p) {
                             const float ss = vh16_sum16((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));      // a head = 16 lanes x 4 columns
                             v = v * vh16_qk_rn(ss, sect == 0 ? sm : 1.0f);
                         } else if (!p.q_l2 && sect == 0) v = v * p.q_plain;
-                        _Float16* dst;
+                        vh_e16* dst;
                         const int ma = p.m_base + m;
                         if (sect == 0) dst = p.q_out + (int64_t)ma * Cq + head * 64;
                         else { const int bb = ma / p.q_l, t = ma - bb * p.q_l; dst = (sect == 1 ? p.q_kc : p.q_vc) + (((int64_t)bb * Hh + head) * p.q_Lmax + p.q_pos0 + t) * 64; }
-                        h4 o; o[0] = (_Float16)v[0]; o[1] = (_Float16)v[1]; o[2] = (_Float16)v[2]; o[3] = (_Float16)v[3];
+                        h4 o; o[0] = (vh_e16)v[0]; o[1] = (vh_e16)v[1]; o[2] = (vh_e16)v[2]; o[3] = (vh_e16)v[3];
                         *(h4*)(dst + (lane & 15) * 4) = o;
                         continue;
                     }
                     if (p.epi == VARHIP_EPI_GELU) { v[0] = vh16_gelu(v[0]); v[1] = vh16_gelu(v[1]); v[2] = vh16_gelu(v[2]); v[3] = vh16_gelu(v[3]); }
                     else if (p.epi == VARHIP_EPI_RESID) {
                         if (p.gamma) v = v * *(const f32x4*)(p.gamma + (int64_t)((p.m_base + m) / p.rows_per_group) * p.ldg + n);
-                        if (p.resid_f16) { const h4 r4 = *(const h4*)((const _Float16*)p.resid + (int64_t)m * p.ldr + n);
+                        if (p.resid_f16) { const h4 r4 = *(const h4*)((const vh_e16*)p.resid + (int64_t)m * p.ldr + n);
                                            v[0] = (float)r4[0] + v[0]; v[1] = (float)r4[1] + v[1]; v[2] = (float)r4[2] + v[2]; v[3] = (float)r4[3] + v[3]; }
                         else v = rcur[rr] + v;
                     }
-                    if (p.out_f16) { h4 o; o[0] = (_Float16)v[0]; o[1] = (_Float16)v[1]; o[2] = (_Float16)v[2]; o[3] = (_Float16)v[3];
+                    if (p.out_f16) { h4 o; o[0] = (vh_e16)v[0]; o[1] = (vh_e16)v[1]; o[2] = (vh_e16)v[2]; o[3] = (vh_e16)v[3];
                                      *(h4*)(Ob + ((int64_t)m * p.ldo + n) * 2) = o; }
                     else *(f32x4*)(Ob + ((int64_t)m * p.ldo + n) * 4) = v;
                 }
@@ -345,11 +348,11 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) k_gemm16(Gemm16P p) {
                     const int rr = rl + RPI * k, m = mrow + rr;
                     if (m >= p.M) continue;
                     const f32x4 w = *(const f32x4*)(stg + rr * SROWW + col * 16);
-                    _Float16* dst;
+                    vh_e16* dst;
                     const int ma = p.m_base + m;
                     if (sect == 0) dst = p.q_out + (int64_t)ma * C + head * 64;
                     else { const int bb = ma / p.q_l, t = ma - bb * p.q_l; dst = (sect == 1 ? p.q_kc : p.q_vc) + (((int64_t)bb * Hh + head) * p.q_Lmax + p.q_pos0 + t) * 64; }
-                    h4 o; o[0] = (_Float16)w[0]; o[1] = (_Float16)w[1]; o[2] = (_Float16)w[2]; o[3] = (_Float16)w[3];
+                    h4 o; o[0] = (vh_e16)w[0]; o[1] = (vh_e16)w[1]; o[2] = (vh_e16)w[2]; o[3] = (vh_e16)w[3];
                     *(h4*)(dst + col * 4) = o;
                 }
                 asm volatile("" ::: "memory");
@@ -394,12 +397,12 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) k_gemm16(Gemm16P p) {
             f32x4 v = *(const f32x4*)(stg + rr * SROWW + col * 16);
             if (p.epi == VARHIP_EPI_RESID) {
                 if (p.gamma) v = v * *(const f32x4*)(p.gamma + (int64_t)((p.m_base + m) / p.rows_per_group) * p.ldg + n);
-                if (p.resid_f16) { const h4 r4 = *(const h4*)((const _Float16*)p.resid + (int64_t)m * p.ldr + n);
+                if (p.resid_f16) { const h4 r4 = *(const h4*)((const vh_e16*)p.resid + (int64_t)m * p.ldr + n);
                                    v[0] = (float)r4[0] + v[0]; v[1] = (float)r4[1] + v[1]; v[2] = (float)r4[2] + v[2]; v[3] = (float)r4[3] + v[3]; }
                 else if constexpr (PRE) v = rpre[i * NIT + k] + v;
                 else v = *(const f32x4*)((const float*)p.resid + (int64_t)m * p.ldr + n) + v;
             }
-            if (p.out_f16) { h4 o; o[0] = (_Float16)v[0]; o[1] = (_Float16)v[1]; o[2] = (_Float16)v[2]; o[3] = (_Float16)v[3];
+            if (p.out_f16) { h4 o; o[0] = (vh_e16)v[0]; o[1] = (vh_e16)v[1]; o[2] = (vh_e16)v[2]; o[3] = (vh_e16)v[3];
                              *(h4*)(Ob + ((int64_t)m * p.ldo + n) * 2) = o; }
             else *(f32x4*)(Ob + ((int64_t)m * p.ldo + n) * 4) = v;
         }
@@ -503,7 +506,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm16p(Gemm16P p) {
 #pragma unroll
                     for (int i = 0; i < TMW; ++i)
 #pragma unroll
-                        for (int j = 0; j < TNW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bn[s2][j], am[i], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < TNW; ++j) acc[i][j] = VH16_MFMA_16x16x32(bn[s2][j], am[i], acc[i][j]);
                     if (s2 == 0) mid();
                 }
             }
@@ -553,23 +556,23 @@ __global__ void __launch_bounds__(512, 2) k_gemm16p(Gemm16P p) {
                             const float ss = vh16_sum16((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));      // a head = 16 lanes x 4 columns
                             v = v * vh16_qk_rn(ss, sect == 0 ? sm : 1.0f);
                         } else if (!p.q_l2 && sect == 0) v = v * p.q_plain;
-                        _Float16* dst;
+                        vh_e16* dst;
                         const int ma = p.m_base + m;
                         if (sect == 0) dst = p.q_out + (int64_t)ma * Cq + head * 64;
                         else { const int bb = ma / p.q_l, t = ma - bb * p.q_l; dst = (sect == 1 ? p.q_kc : p.q_vc) + (((int64_t)bb * Hh + head) * p.q_Lmax + p.q_pos0 + t) * 64; }
-                        h4 o; o[0] = (_Float16)v[0]; o[1] = (_Float16)v[1]; o[2] = (_Float16)v[2]; o[3] = (_Float16)v[3];
+                        h4 o; o[0] = (vh_e16)v[0]; o[1] = (vh_e16)v[1]; o[2] = (vh_e16)v[2]; o[3] = (vh_e16)v[3];
                         if (!(p.dbg & 1)) *(h4*)(dst + (lane & 15) * 4) = o;
                         continue;
                     }
                     if (p.epi == VARHIP_EPI_GELU) { v[0] = vh16_gelu(v[0]); v[1] = vh16_gelu(v[1]); v[2] = vh16_gelu(v[2]); v[3] = vh16_gelu(v[3]); }
                     else if (p.epi == VARHIP_EPI_RESID) {
                         if (p.gamma) v = v * *(const f32x4*)(p.gamma + (int64_t)((p.m_base + m) / p.rows_per_group) * p.ldg + n);
-                        if (p.resid_f16) { const h4 r4 = *(const h4*)((const _Float16*)p.resid + (int64_t)m * p.ldr + n);
+                        if (p.resid_f16) { const h4 r4 = *(const h4*)((const vh_e16*)p.resid + (int64_t)m * p.ldr + n);
                                            v[0] = (float)r4[0] + v[0]; v[1] = (float)r4[1] + v[1]; v[2] = (float)r4[2] + v[2]; v[3] = (float)r4[3] + v[3]; }
                         else v = rcur[rr] + v;
                     }
                     if (p.dbg & 1) { asm volatile("" :: "v"(v)); continue; }
-                    if (p.out_f16) { h4 o; o[0] = (_Float16)v[0]; o[1] = (_Float16)v[1]; o[2] = (_Float16)v[2]; o[3] = (_Float16)v[3];
+                    if (p.out_f16) { h4 o; o[0] = (vh_e16)v[0]; o[1] = (vh_e16)v[1]; o[2] = (vh_e16)v[2]; o[3] = (vh_e16)v[3];
                                      *(h4*)(Ob + ((int64_t)m * p.ldo + n) * 2) = o; }
                     else *(f32x4*)(Ob + ((int64_t)m * p.ldo + n) * 4) = v;
                 }
@@ -587,9 +590,6 @@ __global__ void __launch_bounds__(512, 2) k_gemm16p(Gemm16P p) {
     }
 }
 
-static int g_gemm16_persist = [] { const char* e = getenv("VARHIP_GEMM16_PERSIST"); return e ? (atoi(e) != 0) : 1; }();
-// experiments / A-B: 0 = the 256x256 tile as one workgroup per tile (k_gemm16<8,4,2,4>), 1 (default) = as a persistent workgroup per CU (k_gemm16p)
-extern "C" int varhip_gemm16_persistent(int on) { g_gemm16_persist = on ? 1 : 0; return 0; }
 
 static int launch16p(Gemm16P& p, int batch, hipStream_t stream) {
     static const int dbg = [] { const char* e = getenv("VARHIP_GEMM16_DBG"); return e ? atoi(e) : 0; }();      // experiments only
@@ -625,15 +625,11 @@ static int launch16(Gemm16P& p, int batch, hipStream_t stream) {
     return vh_launch_status();
 }
 
-static int g_gemm16_deep = [] { const char* e = getenv("VARHIP_GEMM16_DEEP"); return e ? (atoi(e) != 0) : 1; }();      // experiments: 0 = the 2-stage small tiles
-static int g_force_tile16 = -1;
-// testing / experiments: force the tile of the next varhip_gemm_nt_f16 / varhip_gemm_qkv_f16 calls (0: 128x128, 1: 64x64 (64x128 for q/k/v), 2: 256x256, -1: automatic)
-extern "C" int varhip_gemm16_force_tile(int tile) { g_force_tile16 = (tile >= 0 && tile <= 2) ? tile : -1; return 0; }
 
 static int pick_tile16(int M, int N, int batch, bool resid32 = false) {
     // 256x256 (8 waves, one workgroup per CU) when it gives every CU at least one tile and rounds of 256 lose little; 128x128 when that fills
     // the chip at least twice over; else 64x64 (K cannot be split without a reduction pass; the small scales are launch-latency bound anyway)
-    if (g_force_tile16 >= 0) return g_force_tile16;
+    if (vh_g_force_tile16 >= 0) return vh_g_force_tile16;
     const int64_t nb256 = (int64_t)((M + 255) / 256) * ((N + 255) / 256) * batch;
     const int64_t nb128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128) * batch;
     // (with the fp32 residual epilogue — attn.proj, ffn.fc2 — the large tile wins earlier: measured at M = 12800, N = 1024, 200 tiles on 256 CUs)
@@ -647,7 +643,7 @@ static int pick_tile16(int M, int N, int batch, bool resid32 = false) {
 // rounds).  Every output element is computed by the same MFMA sequence in either kernel (tests: every tile bit-identical), so the split is
 // invisible in the results.  Returns the number of leading rows for the 256x256 kernel (0: no split, use pick_tile16).
 static int split_rows16(int M, int N, int batch) {
-    if (g_force_tile16 >= 0 || batch != 1) return 0;
+    if (vh_g_force_tile16 >= 0 || batch != 1) return 0;
     static const int off = [] { const char* e = getenv("VARHIP_GEMM16_NOSPLIT"); return e ? atoi(e) : 0; }();       // experiments only
     if (off) return 0;
     const int tilesN = (N + 255) / 256, tilesM = (M + 255) / 256;
@@ -667,7 +663,7 @@ static int run_gemm16(Gemm16P& p, int batch, hipStream_t stream, bool qkv, bool 
     // one launch, or two over row ranges: (a) split_rows16, (b) the persistent 256x256 kernel takes whole tiles only — the last M % 256 rows
     // go to a small-tile launch.  Every launch is timed in the family of ITS kernel.
     const int M = p.M;
-    const bool persist_ok = g_gemm16_persist && (p.N % 256) == 0;
+    const bool persist_ok = vh_g_gemm16_persist && (p.N % 256) == 0;
     struct Seg { int m0, rows, pick; } seg[2];
     int nseg = 1;
     auto small_pick = [&](int rows) { return (int64_t)((rows + 127) / 128) * ((p.N + 127) / 128) >= 384 ? 0 : 1; };
@@ -676,7 +672,7 @@ static int run_gemm16(Gemm16P& p, int batch, hipStream_t stream, bool qkv, bool 
     else {
         const int pick = pick_tile16(M, p.N, batch, resid32);
         seg[0] = {0, M, pick};
-        if (pick == 2 && persist_ok && g_force_tile16 < 0 && batch == 1 && (M % 256) != 0 && M > 256) {
+        if (pick == 2 && persist_ok && vh_g_force_tile16 < 0 && batch == 1 && (M % 256) != 0 && M > 256) {
             seg[0] = {0, M - M % 256, 2}; seg[1] = {M - M % 256, M % 256, small_pick(M % 256)}; nseg = 2;
         }
     }
@@ -685,7 +681,7 @@ static int run_gemm16(Gemm16P& p, int batch, hipStream_t stream, bool qkv, bool 
     for (int i = 0; i < nseg && !rc; ++i) {
         const int m0 = seg[i].m0, rows = seg[i].rows, pick = seg[i].pick;
         p.m_base = m0; p.M = rows;
-        p.A = (const _Float16*)(A0 + (int64_t)m0 * p.lda * 2);
+        p.A = (const vh_e16*)(A0 + (int64_t)m0 * p.lda * 2);
         if (!qkv) {
             p.out = O0 + (int64_t)m0 * p.ldo * (p.out_f16 ? 2 : 4);
             p.resid = R0 ? R0 + (int64_t)m0 * p.ldr * (p.resid_f16 ? 2 : 4) : nullptr;
@@ -697,11 +693,11 @@ static int run_gemm16(Gemm16P& p, int batch, hipStream_t stream, bool qkv, bool 
         if (pick == 2) rc = persistent ? launch16p(p, batch, stream) : launch16<8, 4, 2, 4>(p, batch, stream);
         else rc = small_launch(p, pick, batch, stream);
     }
-    p.M = M; p.m_base = 0; p.A = (const _Float16*)A0; p.out = O0; p.resid = R0;
+    p.M = M; p.m_base = 0; p.A = (const vh_e16*)A0; p.out = O0; p.resid = R0;
     return rc;
 }
 
-extern "C" int varhip_gemm_nt_f16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+extern "C" int VH16_FN(gemm_nt)(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                                   void* out, int64_t ldo, int out_f16, int M, int N, int K, int epi,
                                   const void* resid, int64_t ldr, int resid_f16, const float* gamma, int64_t ldg, int rows_per_group,
                                   int batch, int64_t sA, int64_t sW, int64_t sO, varhip_stream_t stream) {
@@ -713,7 +709,7 @@ extern "C" int varhip_gemm_nt_f16(const void* A, int64_t lda, const void* W, int
         (gamma && ((ldg & 3) || ((uintptr_t)gamma & 15)))) return VARHIP_EINVAL;
     if (M == 0) return 0;
     Gemm16P p{};
-    p.A = (const _Float16*)A; p.W = (const _Float16*)W; p.bias = bias; p.out = out; p.resid = resid; p.gamma = gamma;
+    p.A = (const vh_e16*)A; p.W = (const vh_e16*)W; p.bias = bias; p.out = out; p.resid = resid; p.gamma = gamma;
     p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.ldr = ldr; p.ldg = ldg; p.sA = sA; p.sW = sW; p.sO = sO;
     p.M = M; p.N = N; p.K = K; p.epi = epi; p.rows_per_group = rows_per_group > 0 ? rows_per_group : 1; p.out_f16 = out_f16; p.resid_f16 = resid_f16;
     return run_gemm16(p, batch, (hipStream_t)stream, false, epi == VARHIP_EPI_RESID && !resid_f16,
@@ -721,12 +717,12 @@ extern "C" int varhip_gemm_nt_f16(const void* A, int64_t lda, const void* W, int
                       [](Gemm16P& q, int pick, int b, hipStream_t s) { if (pick == 0) return launch16<4, 4>(q, b, s);
                           // fewer than one 64x64 tile per CU (the first scales: M = 128 .. 512 rows): 32x32 tiles, four times the workgroups, each streaming a
                           // quarter of the bytes per K tile — such a launch is bound by what ONE CU can request per K tile, not by the chip
-                          if (g_gemm16_deep && (int64_t)((q.M + 63) / 64) * ((q.N + 63) / 64) * b < 256) return launch16<1, 1, 2, 2, 4>(q, b, s);
-                          return g_gemm16_deep ? launch16<2, 2, 2, 2, 4>(q, b, s) : launch16<2, 2>(q, b, s); });
+                          if (vh_g_gemm16_deep && (int64_t)((q.M + 63) / 64) * ((q.N + 63) / 64) * b < 256) return launch16<1, 1, 2, 2, 4>(q, b, s);
+                          return vh_g_gemm16_deep ? launch16<2, 2, 2, 2, 4>(q, b, s) : launch16<2, 2>(q, b, s); });
 }
 
 // mat_qkv in the 16-bit mode: fp16 x fp16 -> fp32 accumulators -> (+bias, q/k L2 norm, scale) in fp32 -> fp16 q and fp16 KV-cache rows
-extern "C" int varhip_gemm_qkv_f16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, int M, int C, int K,
+extern "C" int VH16_FN(gemm_qkv)(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, int M, int C, int K,
                                    const float* scale_mul, float plain_scale, int l2norm,
                                    void* q_out, void* kcache, void* vcache, int B2, int l, int H, int pos0, int Lmax, varhip_stream_t stream) {
     if (B2 <= 0 || l <= 0 || H <= 0 || pos0 < 0 || pos0 + l > Lmax || (l2norm && !scale_mul)) return VARHIP_EINVAL;
@@ -734,12 +730,14 @@ extern "C" int varhip_gemm_qkv_f16(const void* A, int64_t lda, const void* W, in
     if (((int64_t)(M - 1) * lda + K) * 2 >= (1ll << 32) || ((int64_t)(3 * C - 1) * ldw + K) * 2 >= (1ll << 32)) return VARHIP_EINVAL;
     if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)bias | (uintptr_t)q_out | (uintptr_t)kcache | (uintptr_t)vcache) & 15)) return VARHIP_EINVAL;
     Gemm16P p{};
-    p.A = (const _Float16*)A; p.W = (const _Float16*)W; p.bias = bias; p.lda = lda; p.ldw = ldw;
+    p.A = (const vh_e16*)A; p.W = (const vh_e16*)W; p.bias = bias; p.lda = lda; p.ldw = ldw;
     p.M = M; p.N = 3 * C; p.K = K; p.epi = 3; p.rows_per_group = 1;
-    p.q_smul = scale_mul; p.q_out = (_Float16*)q_out; p.q_kc = (_Float16*)kcache; p.q_vc = (_Float16*)vcache; p.q_plain = plain_scale;
+    p.q_smul = scale_mul; p.q_out = (vh_e16*)q_out; p.q_kc = (vh_e16*)kcache; p.q_vc = (vh_e16*)vcache; p.q_plain = plain_scale;
     p.q_l2 = l2norm; p.q_l = l; p.q_pos0 = pos0; p.q_Lmax = Lmax;
     return run_gemm16(p, 1, (hipStream_t)stream, true, false, 2.0 * K + 2.0 * 3.0 * C, 2.0 * 3.0 * C * (double)K,
                       [](Gemm16P& q, int pick, int b, hipStream_t s) { if (pick == 0) return launch16<4, 4>(q, b, s);
-                          if (g_gemm16_deep && (int64_t)((q.M + 63) / 64) * ((q.N + 127) / 128) < 256) return launch16<1, 4, 2, 2, 3>(q, b, s);      // 32 rows x one head per wave
-                          return g_gemm16_deep ? launch16<2, 4, 2, 2, 3>(q, b, s) : launch16<2, 4>(q, b, s); });
+                          if (vh_g_gemm16_deep && (int64_t)((q.M + 63) / 64) * ((q.N + 127) / 128) < 256) return launch16<1, 4, 2, 2, 3>(q, b, s);      // 32 rows x one head per wave
+                          return vh_g_gemm16_deep ? launch16<2, 4, 2, 2, 3>(q, b, s) : launch16<2, 4>(q, b, s); });
 }
+
+}  // namespace VH16_NS

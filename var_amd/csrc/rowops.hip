@@ -34,9 +34,8 @@ extern "C" int varhip_add_bcast_f32(const float* base, const float* cond, float*
 // ------------------------------------------------------------------------------------------------------------------
 // AdaLN: one wave per row.  Lane j holds elements 256*t + 4*j + {0..3}: canonical W64(vw=4) partials.
 #define LN_MAXV 10      // C <= 2560
-typedef _Float16 vh_h4 __attribute__((ext_vector_type(4)));
-// OUT16: the result is rounded to fp16 (the A operand of the 16-bit GEMMs); the statistics and the modulation stay fp32
-template <bool OUT16>
+// OUT: 0 = fp32 result; 1 / 2 = rounded to fp16 / bf16 (the A operand of the 16-bit GEMMs); the statistics and the modulation stay fp32
+template <int OUT>
 __global__ void __launch_bounds__(256) k_ln_modulate(const float* __restrict__ x, const float* __restrict__ scale, int64_t lds_,
                                                      const float* __restrict__ shift, int64_t ldh, void* __restrict__ out_,
                                                      int M, int C, int rows_per_group, float eps) {
@@ -81,8 +80,10 @@ __global__ void __launch_bounds__(256) k_ln_modulate(const float* __restrict__ x
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (v[t][e] * rstd) * (s4[e] + 1.0f) + h4[e];
-                if constexpr (OUT16) { vh_h4 o16; o16[0] = (_Float16)o[0]; o16[1] = (_Float16)o[1]; o16[2] = (_Float16)o[2]; o16[3] = (_Float16)o[3];
-                                       *(vh_h4*)((_Float16*)out_ + (int64_t)m * C + i) = o16; }
+                if constexpr (OUT == 1) { typedef _Float16 h4_ __attribute__((ext_vector_type(4))); h4_ o16; o16[0] = (_Float16)o[0]; o16[1] = (_Float16)o[1]; o16[2] = (_Float16)o[2]; o16[3] = (_Float16)o[3];
+                                          *(h4_*)((_Float16*)out_ + (int64_t)m * C + i) = o16; }
+                else if constexpr (OUT == 2) { typedef __bf16 b4_ __attribute__((ext_vector_type(4))); b4_ o16; o16[0] = (__bf16)o[0]; o16[1] = (__bf16)o[1]; o16[2] = (__bf16)o[2]; o16[3] = (__bf16)o[3];
+                                               *(b4_*)((__bf16*)out_ + (int64_t)m * C + i) = o16; }
                 else *(f32x4*)((float*)out_ + (int64_t)m * C + i) = o;
             }
         }
@@ -94,7 +95,7 @@ extern "C" int varhip_ln_modulate_f32(const float* x, const float* scale, int64_
     if (((uintptr_t)x | (uintptr_t)scale | (uintptr_t)shift | (uintptr_t)out) & 15) return VARHIP_EINVAL;
     if (M == 0) return 0;
     VhScope sc(VH_FAM_LN, (hipStream_t)stream, 8.0 * M * C, 8.0 * M * C);
-    hipLaunchKernelGGL(k_ln_modulate<false>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, scale, ld_scale, shift, ld_shift, (void*)out, M, C, rows_per_group, eps);
+    hipLaunchKernelGGL(k_ln_modulate<0>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, scale, ld_scale, shift, ld_shift, (void*)out, M, C, rows_per_group, eps);
     return vh_launch_status();
 }
 extern "C" int varhip_ln_modulate_f16out(const float* x, const float* scale, int64_t ld_scale, const float* shift, int64_t ld_shift,
@@ -103,7 +104,16 @@ extern "C" int varhip_ln_modulate_f16out(const float* x, const float* scale, int
     if (((uintptr_t)x | (uintptr_t)scale | (uintptr_t)shift | (uintptr_t)out) & 15) return VARHIP_EINVAL;
     if (M == 0) return 0;
     VhScope sc(VH_FAM_LN, (hipStream_t)stream, 8.0 * M * C, 6.0 * M * C);
-    hipLaunchKernelGGL(k_ln_modulate<true>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, scale, ld_scale, shift, ld_shift, out, M, C, rows_per_group, eps);
+    hipLaunchKernelGGL(k_ln_modulate<1>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, scale, ld_scale, shift, ld_shift, out, M, C, rows_per_group, eps);
+    return vh_launch_status();
+}
+extern "C" int varhip_ln_modulate_bf16out(const float* x, const float* scale, int64_t ld_scale, const float* shift, int64_t ld_shift,
+                                         void* out, int M, int C, int rows_per_group, float eps, varhip_stream_t stream) {
+    if (M < 0 || C <= 0 || (C & 3) || C > 256 * LN_MAXV || rows_per_group <= 0 || (ld_scale & 3) || (ld_shift & 3)) return VARHIP_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)scale | (uintptr_t)shift | (uintptr_t)out) & 15) return VARHIP_EINVAL;
+    if (M == 0) return 0;
+    VhScope sc(VH_FAM_LN, (hipStream_t)stream, 8.0 * M * C, 6.0 * M * C);
+    hipLaunchKernelGGL(k_ln_modulate<2>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, scale, ld_scale, shift, ld_shift, out, M, C, rows_per_group, eps);
     return vh_launch_status();
 }
 

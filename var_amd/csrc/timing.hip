@@ -45,7 +45,20 @@ void vh_timing_end(int fam, hipStream_t s) {
     if (g_used < g_pool.size()) { (void)hipEventRecord(g_pool[g_used].b, s); ++g_used; }
 }
 
+// switches shared by the fp16 and bf16 builds of the 16-bit kernels (elem16.h); the environment variables are for experiments
+int vh_g_force_tile16 = -1;
+int vh_g_gemm16_persist = [] { const char* e = getenv("VARHIP_GEMM16_PERSIST"); return e ? (atoi(e) != 0) : 1; }();
+int vh_g_gemm16_deep = [] { const char* e = getenv("VARHIP_GEMM16_DEEP"); return e ? (atoi(e) != 0) : 1; }();       // 0: the 2-stage 64-row tiles only
+int vh_g_conv16_force_wm = 0;
+
 extern "C" {
+
+// testing / experiments: force the tile of the next 16-bit GEMM calls (0: 128x128, 1: 64x64 and smaller (64x128 for q/k/v), 2: 256x256, -1: automatic)
+int varhip_gemm16_force_tile(int tile) { vh_g_force_tile16 = (tile >= 0 && tile <= 2) ? tile : -1; return 0; }
+// 0 = whole 256x256 tiles on k_gemm16<8,4,2,4> (one workgroup per tile), 1 (default) = on the persistent k_gemm16p
+int varhip_gemm16_persistent(int on) { vh_g_gemm16_persist = on ? 1 : 0; return 0; }
+// 0: by size; 2 / 4 / 8: force the 128-pixel / 256-pixel / halo-patch conv kernel (tests, tools/bench_kernels.py)
+int varhip_conv16_force_tile(int wm) { vh_g_conv16_force_wm = (wm == 2 || wm == 4 || wm == 8) ? wm : 0; return 0; }
 
 const char* varhip_version(void) { return "var_hip 0.1.0 gfx950"; }
 

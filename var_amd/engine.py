@@ -49,6 +49,10 @@ def phi_index(si: int, S: int, K: int) -> int:
     return int(np.argmin(np.abs(ticks - si / (S - 1)))) if S > 1 else 0
 
 
+PRECISIONS = ('f32', 'f16', 'bf16')
+DT16 = {'f16': torch.float16, 'bf16': torch.bfloat16}      # storage type of the two 16-bit flavours (include/var_hip.h "f16" / "bf16")
+
+
 def _ver(p: torch.Tensor) -> int:
     """version counter of a parameter; tensors created under torch.inference_mode() have none"""
     try:
@@ -120,8 +124,8 @@ class DecoderEngine(_VaeOps):
     precision = 'f32'
 
     def set_precision(self, precision: str):
-        if precision not in ('f32', 'f16'):
-            raise ValueError("precision must be 'f32' or 'f16'")
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision must be one of {PRECISIONS}")
         self.precision = precision
 
     def refresh(self):
@@ -135,15 +139,17 @@ class DecoderEngine(_VaeOps):
             hip.call('upconv_pack_f32', w[k], wp, cin, cout)
             w[k[:-len('weight')] + 'phase'] = wp
         self.w = w
-        self.w16 = {}                        # fp16 copies: made by _ensure16() the first time a 16-bit decode runs on these weights
+        self.w16s = {}                       # {'f16' | 'bf16': 16-bit copies}: made by _ensure16() the first time such a decode runs on these weights
         self.nlev = 1 + max(int(k.split('.')[2]) for k in w if k.startswith('decoder.up.'))
         self._sig = sig
 
-    def _ensure16(self):
-        """fp16 copies of every conv kernel (3x3, phase, 1x1 shortcut) next to the fp32 ones; biases and GroupNorm affine stay fp32"""
-        if not self.w16:
-            self.w16 = {k: v.to(torch.float16).contiguous() for k, v in self.w.items()
-                        if (k.endswith('.weight') or k.endswith('.phase')) and v.dim() >= 2 and '.norm' not in k}
+    def _ensure16(self, prec):
+        """16-bit copies of every conv kernel (3x3, phase, 1x1 shortcut, attention projections) next to the fp32 ones; biases and GroupNorm affine
+        stay fp32.  Selects them (self.w16) and the flavour's entry-point suffix / dtype for the decode that follows."""
+        if prec not in self.w16s:
+            self.w16s[prec] = {k: v.to(DT16[prec]).contiguous() for k, v in self.w.items()
+                               if (k.endswith('.weight') or k.endswith('.phase')) and v.dim() >= 2 and '.norm' not in k}
+        self.w16, self.sfx, self.dt16 = self.w16s[prec], prec, DT16[prec]
 
     # -- building blocks ---------------------------------------------------------------------------------------------
     def _part_buffer(self, B, nblk, Cout, dev):
@@ -248,10 +254,10 @@ class DecoderEngine(_VaeOps):
     def conv3_16(self, x, key, B, Hh, Ww, resid=None, out_mode=0, stats=False):
         wt = self.w16[key + '.weight']
         Cout, Cin = wt.shape[0], wt.shape[3]
-        out = torch.empty((B, Cout, Hh, Ww), dtype=torch.float32, device=x.device) if out_mode else torch.empty((B, Hh, Ww, Cout), dtype=torch.float16, device=x.device)
+        out = torch.empty((B, Cout, Hh, Ww), dtype=torch.float32, device=x.device) if out_mode else torch.empty((B, Hh, Ww, Cout), dtype=self.dt16, device=x.device)
         nblk = hip.conv_gn_blocks(Hh, Ww, Cout) if (stats and out_mode == 0 and Cout % 4 == 0) else 0
         part = self._part_buffer(B, nblk, Cout, x.device) if nblk else None
-        hip.call('conv3x3_nhwc_f16', x, wt, self.w[key + '.bias'], resid, out, part, B, Hh, Ww, Cin, Cout, out_mode)
+        hip.call('conv3x3_nhwc_' + self.sfx, x, wt, self.w[key + '.bias'], resid, out, part, B, Hh, Ww, Cin, Cout, out_mode)
         if nblk: self._gn_part = (out, part, nblk)
         return out
 
@@ -264,9 +270,9 @@ class DecoderEngine(_VaeOps):
             hip.call('gn_stats_part_f32', pend[1], stats, B, pend[2], HW, Cc, 32, 1e-6)
         else:
             scratch = torch.empty(hip.gn_scratch_elems(B, HW, Cc, 32), dtype=torch.float64, device=x.device)
-            hip.call('gn_stats_f16', x, stats, scratch, B, HW, Cc, 32, 1e-6)
+            hip.call('gn_stats_' + self.sfx, x, stats, scratch, B, HW, Cc, 32, 1e-6)
         out = torch.empty_like(x)
-        hip.call('gn_apply_f16', x, stats, self.w[key + '.weight'], self.w[key + '.bias'], out, B, HW, Cc, 32, int(silu))
+        hip.call('gn_apply_' + self.sfx, x, stats, self.w[key + '.weight'], self.w[key + '.bias'], out, B, HW, Cc, 32, int(silu))
         return out
 
     def resblock16(self, x, pre, B, Hh, Ww):
@@ -277,8 +283,8 @@ class DecoderEngine(_VaeOps):
         if (pre + '.nin_shortcut.weight') in self.w16:              # 1x1 conv == fp16 GEMM over the pixels
             wt = self.w16[pre + '.nin_shortcut.weight']
             N, K = wt.shape
-            sc = torch.empty((B, Hh, Ww, N), dtype=torch.float16, device=x.device)
-            hip.call('gemm_nt_f16', x, K, wt, K, self.w[pre + '.nin_shortcut.bias'], sc, N, 1, B * HW, N, K, EPI_NONE, None, 0, 0, None, 0, 1, 1, 0, 0, 0)
+            sc = torch.empty((B, Hh, Ww, N), dtype=self.dt16, device=x.device)
+            hip.call('gemm_nt_' + self.sfx, x, K, wt, K, self.w[pre + '.nin_shortcut.bias'], sc, N, 1, B * HW, N, K, EPI_NONE, None, 0, 0, None, 0, 1, 1, 0, 0, 0)
         return self.conv3_16(hn, pre + '.conv2', B, Hh, Ww, resid=sc, stats=True)
 
     def attnblock16(self, x, pre, B, Hh, Ww):
@@ -286,19 +292,19 @@ class DecoderEngine(_VaeOps):
         on the f16 MFMA GEMM with fp32 accumulation; scores and softmax in fp32, the probabilities rounded to fp16 for p.v"""
         HW, Cc = Hh * Ww, x.shape[-1]
         dev = x.device
-        f16 = torch.float16
+        f16 = self.dt16
         if Cc % 64 or HW % 64:                     # (tiny test configurations: the f16 GEMM contracts 64 at a time) fp32 attention between two casts
             x32 = torch.empty(x.shape, dtype=torch.float32, device=dev)
-            hip.call('cast_f16_to_f32', x, x32, x.numel())
+            hip.call(f'cast_{self.sfx}_to_f32', x, x32, x.numel())
             self._gn_part = None
             y32 = self.attnblock(x32, pre, B, Hh, Ww)
             y = torch.empty(x.shape, dtype=f16, device=dev)
-            hip.call('cast_f32_to_f16', y32, y, y.numel())
+            hip.call('cast_f32_to_' + self.sfx, y32, y, y.numel())
             return y
         xn = self.gn16(x, pre + '.norm', B, HW, False).view(B * HW, Cc)
         wqkv, bqkv = self.w16[pre + '.qkv.weight'], self.w[pre + '.qkv.bias']
         g16 = lambda A, lda, W, ldw, bias, out, ldo, o16, M, N, K, epi=EPI_NONE, resid=None, ldr=0, r16=0, batch=1, sA=0, sW=0, sO=0: \
-            hip.call('gemm_nt_f16', A, lda, W, ldw, bias, out, ldo, o16, M, N, K, epi, resid, ldr, r16, None, 0, 1, batch, sA, sW, sO)
+            hip.call('gemm_nt_' + self.sfx, A, lda, W, ldw, bias, out, ldo, o16, M, N, K, epi, resid, ldr, r16, None, 0, 1, batch, sA, sW, sO)
         qk = torch.empty((B * HW, 2 * Cc), dtype=f16, device=dev)
         g16(xn, Cc, wqkv, Cc, bqkv, qk, 2 * Cc, 1, B * HW, 2 * Cc, Cc)
         # V^T[b][c][j] WITHOUT its bias: the GEMM's bias is per column and here c is the row.  The rows of p sum to one, so the bias is added
@@ -310,7 +316,7 @@ class DecoderEngine(_VaeOps):
         p32 = torch.empty_like(s)
         hip.call('softmax_rows_f32', s, p32, B * HW, HW, float(np.float32(int(Cc) ** (-0.5))))
         p = torch.empty((B, HW, HW), dtype=f16, device=dev)
-        hip.call('cast_f32_to_f16', p32, p, p.numel())
+        hip.call('cast_f32_to_' + self.sfx, p32, p, p.numel())
         o = torch.empty((B * HW, Cc), dtype=f16, device=dev)
         g16(p, HW, vt, HW, bqkv[2 * Cc:], o, Cc, 1, HW, Cc, HW, batch=B, sA=HW * HW, sW=Cc * HW, sO=HW * Cc)
         y = torch.empty((B, Hh, Ww, Cc), dtype=f16, device=dev)
@@ -320,8 +326,8 @@ class DecoderEngine(_VaeOps):
     def _decode16(self, f_hat: torch.Tensor, denorm: bool) -> torch.Tensor:
         B, P = f_hat.shape[0], f_hat.shape[1]
         Hh = Ww = P
-        x = torch.empty(f_hat.shape, dtype=torch.float16, device=f_hat.device)
-        hip.call('cast_f32_to_f16', f_hat.contiguous(), x, x.numel())
+        x = torch.empty(f_hat.shape, dtype=self.dt16, device=f_hat.device)
+        hip.call('cast_f32_to_' + self.sfx, f_hat.contiguous(), x, x.numel())
         h = self.conv3_16(x, 'post_quant_conv', B, Hh, Ww)
         h = self.conv3_16(h, 'decoder.conv_in', B, Hh, Ww, stats=True)
         h = self.resblock16(h, 'decoder.mid.block_1', B, Hh, Ww)
@@ -336,10 +342,10 @@ class DecoderEngine(_VaeOps):
                 Hh, Ww = 2 * Hh, 2 * Ww
                 key = f'decoder.up.{lev}.upsample.conv'
                 wp = self.w16[key + '.phase']
-                up = torch.empty((B, Hh, Ww, wp.shape[1]), dtype=torch.float16, device=h.device)
+                up = torch.empty((B, Hh, Ww, wp.shape[1]), dtype=self.dt16, device=h.device)
                 nblk = hip.conv_gn_blocks(Hh, Ww, wp.shape[1], phase=True)
                 part = self._part_buffer(B, nblk, wp.shape[1], h.device) if nblk else None
-                hip.call('upconv_phase_f16', h, wp, self.w[key + '.bias'], up, part, B, Hh, Ww, wp.shape[4], wp.shape[1])
+                hip.call('upconv_phase_' + self.sfx, h, wp, self.w[key + '.bias'], up, part, B, Hh, Ww, wp.shape[4], wp.shape[1])
                 self._gn_part = (up, part, nblk) if nblk else None
                 h = up
         h = self.gn16(h, 'decoder.norm_out', B, Hh * Ww, True)
@@ -348,10 +354,11 @@ class DecoderEngine(_VaeOps):
     def decode_nhwc(self, f_hat: torch.Tensor, denorm: bool = True, precision: Optional[str] = None) -> torch.Tensor:
         """[B,P,P,Cvae] channels-last -> [B,3,16P,16P]; denorm=True: in [0,1] (clamp and (x+1)/2 fused into the last conv, what
         autoregressive_infer_cfg returns); denorm=False: clamped to [-1,1] (VQVAE.fhat_to_img's contract).
-        precision: 'f32' / 'f16' for THIS call (None: the engine's default, `self.precision`)"""
+        precision: 'f32' / 'f16' / 'bf16' for THIS call (None: the engine's default, `self.precision`)"""
         self.refresh()
-        if (precision or self.precision) == 'f16':
-            self._ensure16()
+        prec = precision or self.precision
+        if prec != 'f32':
+            self._ensure16(prec)
             return self._decode16(f_hat, denorm)
         B, P = f_hat.shape[0], f_hat.shape[1]
         Hh = Ww = P
@@ -575,9 +582,9 @@ class SamplingEngine:
                 d['gss'] = g(b.ada_gss, 'ada_gss').view(-1)
             else:
                 d['ada_w'], d['ada_b'] = g(b.ada_lin[1].weight, 'ada_lin'), g(b.ada_lin[1].bias, 'ada_lin')
-            if self.precision == 'f16':      # fp16 copies of the four GEMM weights (round-to-nearest-even, once per weight change)
+            if self.precision != 'f32':      # 16-bit copies of the four GEMM weights (round-to-nearest-even, once per weight change)
                 for k in ('qkv_w', 'proj_w', 'fc1_w', 'fc2_w'):
-                    d[k + '16'] = d[k].to(torch.float16).contiguous()
+                    d[k + '16'] = d[k].to(DT16[self.precision]).contiguous()
             blocks.append(d)
         w['blocks'] = blocks
         if not var.shared_aln and var.depth * 6 * C * C * 4 < 3.5e9:          # (beyond: the weight rows would leave the GEMM's 32-bit request offsets)
@@ -585,8 +592,8 @@ class SamplingEngine:
             # workgroup's K loop (29 us each at d16); the packed copy (0.4 GB fp32 at d16) is rebuilt with the other copies when weights change
             w['ada_w_all'] = torch.cat([d['ada_w'] for d in blocks], dim=0).contiguous()
             w['ada_b_all'] = torch.cat([d['ada_b'] for d in blocks], dim=0).contiguous()
-        if self.precision == 'f16':
-            w['head_w16'] = w['head_w'].to(torch.float16).contiguous()
+        if self.precision != 'f32':
+            w['head_w16'] = w['head_w'].to(DT16[self.precision]).contiguous()
         w['codebook'] = g(quant.embedding.weight, 'codebook')
         w['codebook_T'] = w['codebook'].t().contiguous()          # [Cvae][V]: "probabilities @ codebook" as an NT GEMM (more_smooth)
         phis = list(quant.quant_resi.phis())
@@ -601,13 +608,13 @@ class SamplingEngine:
         self._sig = sig
 
     def set_precision(self, precision: str):
-        """'f32' (default; the parity contract: token ids bit-identical to the CPU oracle) or 'f16': fp16 weights / GEMM operands / KV
+        """'f32' (default; the parity contract: token ids bit-identical to the CPU oracle), 'f16' or 'bf16': 16-bit weights / GEMM operands / KV
         cache with fp32 accumulation on the f16 MFMAs — what the reference's harness asks for with torch.autocast(fp16)
         (demo_sample.py:66-68), and the decoder call that ends the loop runs on fp16 activations / conv weights too (conv16.hip).  LayerNorm /
         GroupNorm statistics, AdaLN parameters, the residual stream, softmax, logits, sampler and quantizer stay fp32.  The VQVAE's own entry
         points (fhat_to_img, idxBl_to_img, ...) are NOT switched: the shared DecoderEngine is told the precision per call."""
-        if precision not in ('f32', 'f16'):
-            raise ValueError("precision must be 'f32' or 'f16'")
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision must be one of {PRECISIONS}")
         if precision != self.precision:
             self.precision = precision
             self._sig = None
@@ -631,7 +638,7 @@ class SamplingEngine:
         M = 2 * B * lmax
         hid = var.blocks[0].ffn.fc1.weight.shape[0]
         e = lambda *s, dt=torch.float32: torch.empty(*s, dtype=dt, device=dev)
-        act = torch.float16 if self.precision == 'f16' else torch.float32       # GEMM operands and KV cache; x / x2 / logits stay fp32
+        act = DT16.get(self.precision, torch.float32)                           # GEMM operands and KV cache; x / x2 / logits stay fp32
         ws = dict(dev=dev, x=e(M, C), x2=e(M, C), xn=e(M, C, dt=act), q=e(M, C, dt=act), att=e(M, C, dt=act), hid=e(M, hid, dt=act), logits=e(M, V),
                   idx=e(B * lmax, dt=torch.int64), lvl_pos=e(L, C), cond=e(2 * B, C), cond_silu=e(2 * B, C), hn=e(2 * B, 2 * C),
                   ada=e(var.depth, 2 * B, 6 * C) if var.shared_aln else e(2 * B, var.depth * 6 * C), shared=e(2 * B, 6 * C) if var.shared_aln else None,
@@ -663,8 +670,8 @@ class SamplingEngine:
         """one AdaLNSelfAttn block (basic_var.py:152-159): seven launches behind one library call; the result is left in x"""
         var = self.var
         C = var.C
-        if self.precision == 'f16':
-            hip.call('adaln_block_f16', x, x2, ws['xn'], ws['q'], ws['att'], ws['hid'], ws['ada_view'][bi][0], ws['ada_view'][bi][1],
+        if self.precision != 'f32':
+            hip.call('adaln_block_' + self.precision, x, x2, ws['xn'], ws['q'], ws['att'], ws['hid'], ws['ada_view'][bi][0], ws['ada_view'][bi][1],
                      blk['qkv_w16'], blk['qkv_b'], blk['smul'], blk['plain_scale'], int(blk['l2']), blk['proj_w16'], blk['proj_b'],
                      blk['fc1_w16'], blk['fc1_b'], blk['fc2_w16'], blk['fc2_b'], ws['kc'][bi], ws['vc'][bi],
                      rows, l, C, var.num_heads, blk['fc1_w'].shape[0], cur, var.L, var.norm_eps)
@@ -678,9 +685,9 @@ class SamplingEngine:
         """get_logits (var.py:118-124): AdaLNBeforeHead (LayerNorm + scale/shift) then the vocabulary projection -> fp32 logits"""
         var, w = self.var, self.w
         C, V = var.C, var.V
-        if self.precision == 'f16':
-            hip.call('ln_modulate_f16out', x, hn, 2 * C, hn[:, C:], 2 * C, xn, M, C, l, var.norm_eps)
-            hip.call('gemm_nt_f16', xn, C, w['head_w16'], C, w['head_b'], logits, V, 0, M, V, C, EPI_NONE, None, 0, 0, None, 0, 1, 1, 0, 0, 0)
+        if self.precision != 'f32':
+            hip.call(f'ln_modulate_{self.precision}out', x, hn, 2 * C, hn[:, C:], 2 * C, xn, M, C, l, var.norm_eps)
+            hip.call('gemm_nt_' + self.precision, xn, C, w['head_w16'], C, w['head_b'], logits, V, 0, M, V, C, EPI_NONE, None, 0, 0, None, 0, 1, 1, 0, 0, 0)
         else:
             hip.call('ln_modulate_f32', x, hn, 2 * C, hn[:, C:], 2 * C, xn, M, C, l, var.norm_eps)
             self.gemm(xn, w['head_w'], w['head_b'], logits, M)
@@ -874,7 +881,7 @@ class SamplingEngine:
         ws = self._ws_tf.get(R) if hasattr(self, '_ws_tf') else None
         if ws is None or ws['dev'] != dev:
             e = lambda *s, dt=torch.float32: torch.empty(*s, dtype=dt, device=dev)
-            act = torch.float16 if self.precision == 'f16' else torch.float32
+            act = DT16.get(self.precision, torch.float32)
             M = R * lmax
             # x is written by first_map_f32 / word_embed_f32, which also emit the CFG copy of every row (unused here): room for 2x
             ws = dict(dev=dev, x=e(2 * M, C), x2=e(M, C), xn=e(M, C, dt=act), q=e(M, C, dt=act), att=e(M, C, dt=act), hid=e(M, hid, dt=act), lg=e(R * lmax, V),
