@@ -313,6 +313,11 @@ int varhip_gn_stats_f16(const void* x, float* stats, double* scratch, int B, int
 int varhip_gn_apply_f16(const void* x, const float* stats, const float* gamma, const float* beta, void* out,
                         int B, int HW, int C, int G, int silu, varhip_stream_t stream);
 /* casts at the edges of the mode (n % 4 == 0, 16-byte aligned) */
+/* the decoder's tail in one pass (basic_vae.py:224-226 norm_out -> swish -> conv_out, the caller's clamp vqvae.py:63 and (x + 1) / 2 var.py:190):
+ * out = clamp(conv3x3(SiLU(GroupNorm(x))) + bias) as fp32 NCHW (out_mode 2) or de-normalised to [0, 1] (out_mode 1); stats [B][G][2] = (mean, rstd).
+ * Bit-identical to varhip_gn_apply_f16 followed by varhip_conv3x3_nhwc_f16.  Shapes it does not take (H % 8, W % 32, Cin % 32, Cout > 16): VARHIP_EINVAL. */
+int varhip_gn_silu_conv_out_f16(const void* x, const float* stats, const float* gamma, const float* beta, const void* w, const float* bias,
+                                float* out, int B, int H, int W, int Cin, int Cout, int G, int out_mode, varhip_stream_t stream);
 int varhip_cast_f32_to_f16(const float* in, void* out, int64_t n, varhip_stream_t stream);
 int varhip_cast_f16_to_f32(const void* in, float* out, int64_t n, varhip_stream_t stream);
 
@@ -346,6 +351,8 @@ int varhip_conv16_force_tile(int wm);
 int varhip_gn_stats_bf16(const void* x, float* stats, double* scratch, int B, int HW, int C, int G, float eps, varhip_stream_t stream);
 int varhip_gn_apply_bf16(const void* x, const float* stats, const float* gamma, const float* beta, void* out,
                         int B, int HW, int C, int G, int silu, varhip_stream_t stream);
+int varhip_gn_silu_conv_out_bf16(const void* x, const float* stats, const float* gamma, const float* beta, const void* w, const float* bias,
+                                 float* out, int B, int H, int W, int Cin, int Cout, int G, int out_mode, varhip_stream_t stream);
 int varhip_cast_f32_to_bf16(const float* in, void* out, int64_t n, varhip_stream_t stream);
 int varhip_cast_bf16_to_f32(const void* in, float* out, int64_t n, varhip_stream_t stream);
 

@@ -369,6 +369,39 @@ def test_groupnorm16_against_float64(B, HW, C, silu):
     assert torch.equal(y32, out.float()) and torch.equal(back, out)
 
 
+@pytest.mark.parametrize('flav', ['f16', 'bf16'])
+@pytest.mark.parametrize('B,H,W,Cin,Cout,omode', [(2, 8, 32, 32, 3, 1), (1, 64, 64, 160, 3, 2), (3, 16, 96, 64, 3, 1), (1, 24, 32, 96, 8, 2), (2, 256, 256, 160, 3, 1)])
+def test_gn_silu_conv_out_fused_equals_two_launches(flav, B, H, W, Cin, Cout, omode):
+    """the decoder's tail (norm_out -> swish -> conv_out -> clamp, basic_vae.py:224-226) in one pass against GroupNorm apply + conv3x3 as two
+    launches: identical bits (same arithmetic per element, same MFMA sequence), edge patches and the image border included; and against float64"""
+    hip = _hip()
+    dt = torch.float16 if flav == 'f16' else torch.bfloat16
+    g = torch.Generator().manual_seed(H * 7 + W + Cin)
+    x = (torch.randn(B, H, W, Cin, generator=g) * 1.3 + 0.2).to(dt).cuda()
+    w = (torch.randn(Cout, 3, 3, Cin, generator=g) * (2.0 / (9 * Cin) ** 0.5)).to(dt).cuda()
+    bias = (torch.randn(Cout, generator=g) * 0.1).cuda()
+    gamma, beta = (torch.randn(Cin, generator=g) * 0.2 + 1.0).cuda(), (torch.randn(Cin, generator=g) * 0.2).cuda()
+    stats = torch.empty(B, 32, 2, dtype=torch.float32, device='cuda')
+    scratch = torch.empty(hip.gn_scratch_elems(B, H * W, Cin, 32), dtype=torch.float64, device='cuda')
+    hip.call('gn_stats_' + flav, x, stats, scratch, B, H * W, Cin, 32, 1e-6)
+    fused = torch.full((B, Cout, H, W), float('nan'), dtype=torch.float32, device='cuda')
+    hip.call('gn_silu_conv_out_' + flav, x, stats, gamma, beta, w, bias, fused, B, H, W, Cin, Cout, 32, omode)
+    xn = torch.empty_like(x)
+    hip.call('gn_apply_' + flav, x, stats, gamma, beta, xn, B, H * W, Cin, 32, 1)
+    two = torch.empty_like(fused)
+    hip.call('conv3x3_nhwc_' + flav, xn, w, bias, None, two, None, B, H, W, Cin, Cout, omode)
+    assert torch.equal(fused, two), f'fused tail differs from the two launches in {int((fused != two).sum())} elements, max {float((fused - two).abs().max()):.3e}'
+    if B * H * W <= 70000:
+        ref = torch.nn.functional.conv2d(xn.double().cpu().permute(0, 3, 1, 2), w.double().cpu().permute(0, 3, 1, 2), bias.double().cpu(), padding=1).clamp(-1, 1)
+        if omode == 1: ref = (ref + 1) * 0.5
+        assert float((fused.double().cpu() - ref).abs().max()) <= 1e-5 + 2e-6 * (9 * Cin) ** 0.5
+    # shapes it does not take are refused, not mis-computed
+    from var_amd import abi
+    assert hip.lib().so.varhip_gn_silu_conv_out_f16 is not None
+    with pytest.raises(Exception):
+        hip.call('gn_silu_conv_out_' + flav, x, stats, gamma, beta, w, bias, fused, B, H - 1, W, Cin, Cout, 32, omode)
+
+
 def test_decoder16_vs_fp32_decoder():
     """VQVAE.fhat_to_img in the 16-bit mode against the fp32 HIP decoder on the same f_hat (d16-size decoder, 256x256, B=2)"""
     z, meta = util.load_case('d16_full')
@@ -385,6 +418,13 @@ def test_decoder16_vs_fp32_decoder():
             vae._decoder_engine().set_precision('f32')
         c = vae.fhat_to_img(f_hat)
     assert torch.equal(b, b2) and torch.equal(a, c)
+    eng = vae._decoder_engine()
+    eng.set_precision('f16'); eng.unfused_tail = True           # norm_out / conv_out as two launches: the same image bit for bit
+    try:
+        with torch.inference_mode(): b3 = vae.fhat_to_img(f_hat).clone()
+    finally:
+        eng.set_precision('f32'); eng.unfused_tail = False
+    assert torch.equal(b, b3)
     d = (a - b).abs()
     print(f'decoder f16 vs f32: max |d| {float(d.max()):.3e}, mean |d| {float(d.mean()):.3e} (range [-1, 1])')
     assert float(d.max()) <= 5e-2 and float(d.mean()) <= 4e-3 and torch.isfinite(b).all()

@@ -63,6 +63,7 @@ SIGNATURES_F16 = {
     'upconv_phase_f16':  [P, P, P, P, P, I, I, I, I, I],
     'gn_stats_f16':      [P, P, P, I, I, I, I, F],
     'gn_apply_f16':      [P, P, P, P, P, I, I, I, I, I],
+    'gn_silu_conv_out_f16': [P, P, P, P, P, P, P, I, I, I, I, I, I, I],
     'cast_f32_to_f16':   [P, P, L],
     'cast_f16_to_f32':   [P, P, L],
 }

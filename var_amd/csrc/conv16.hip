@@ -543,4 +543,154 @@ extern "C" int VH16_FN(upconv_phase)(const void* in, const void* w_phase, const 
     return dispatch_conv16(p, 4, (hipStream_t)stream);
 }
 
+
+// ---- k_gnconv16o: the decoder's tail  norm_out -> SiLU -> conv_out  (basic_vae.py:224-226: GroupNorm(32) + swish + conv3x3 to 3 channels,
+// then the caller's clamp / (x + 1) / 2: vqvae.py:63, var.py:190) in ONE pass over the 160-channel map.
+// As two launches this was the decoder's worst pair: the apply pass reads and writes the 256x256x160 map (2.7 GB at B = 64: HBM-bound), and
+// the 3-channel convolution on the 128-pixel kernel re-reads every input pixel once per tap through L2 (12 GB into LDS for 0.04 TFLOP).
+// Here a workgroup of 4 waves owns an 8 x 32 patch of one image.  Per 32-channel chunk its (8+2) x (32+2) halo patch goes
+// global -> registers -> (x * sc + sh, SiLU, one rounding to the 16-bit type: k_gn16_apply's arithmetic, operation for operation) -> LDS,
+// out-of-image pixels as zeros (the convolution pads the NORMALISED map), and the nine taps read it at nine row offsets; the next chunk's
+// loads are in flight while the taps run.  K order = chunk outermost, then tap, one 16x16x32 step each, weights as the A operand: the MFMA
+// sequence of k_conv16 — the fused result is bit-identical to gn_apply followed by conv3x3_nhwc (tests).  All weights (Cout x 9 x Cin, 8.6 KB) stay in LDS.
+struct GnConvOP {
+    const vh_e16* in; const float* stats; const float* gamma; const float* beta; const vh_e16* w; const float* bias; float* out;
+    int H, Wd, Cin, N, G, out_mode;
+};
+__global__ void __launch_bounds__(256) k_gnconv16o(GnConvOP p) {
+    constexpr int PH = 8, PW = 32, P = PW + 2, PROWS = (PH + 2) * P, ROWB = 64, PATCH = PROWS * ROWB, NPC = (PROWS * 4 + 255) / 256;      // (2 x 21.25 KB of patch + weights + table = 52.2 KB at 160 -> 3: three workgroups per CU)
+    extern __shared__ __attribute__((aligned(16))) char smo[];
+    char* const sW = smo + 2 * PATCH;                                   // [N][9 * Cin] halves
+    float* const sSc = reinterpret_cast<float*>(sW + ((p.N * 9 * p.Cin * 2 + 15) & ~15));      // [Cin] scale, then [Cin] shift
+    float* const sSh = sSc + p.Cin;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tX = p.Wd / PW, tY = p.H / PH, tps = tX * tY;
+    const int b = blockIdx.x / tps, trem = blockIdx.x - b * tps, tyi = trem / tX, ty0 = tyi * PH, tx0 = (trem - tyi * tX) * PW;
+    const int hw = p.H * p.Wd, K = 9 * p.Cin, nch = p.Cin / 32;
+    // prologue: weights and the sample's (scale, shift) per channel to LDS
+    for (int e = tid; e < p.N * K / 8; e += 256) *(h8*)(sW + e * 16) = *(const h8*)(p.w + (int64_t)e * 8);
+    for (int c = tid; c < p.Cin; c += 256) {
+        const float* st = p.stats + ((int64_t)b * p.G + c / (p.Cin / p.G)) * 2;
+        const float sc = st[1] * p.gamma[c];
+        sSc[c] = sc; sSh[c] = p.beta[c] - st[0] * sc;
+    }
+    // this thread's pieces of a patch chunk: piece e = tid + 256 k -> patch row e >> 2, 8-channel slot e & 3 (= tid & 3 for every k)
+    const int slot = tid & 3;
+    uint32_t goff[NPC]; int loff[NPC]; uint32_t okmask = 0;
+    const vh_e16* const src = p.in + (int64_t)b * hw * p.Cin + slot * 8;
+#pragma unroll
+    for (int k = 0; k < NPC; ++k) {
+        const int pr = (tid + 256 * k) >> 2, py = pr / P, px = pr - py * P, y = ty0 - 1 + py, x = tx0 - 1 + px;
+        const bool in_patch = pr < PROWS, ok = in_patch && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.Wd;
+        goff[k] = ok ? (uint32_t)((y * p.Wd + x) * p.Cin) : 0u;
+        loff[k] = in_patch ? pr * ROWB + ((slot ^ (((pr >> 2) & 1) << 1)) << 4) : -1;
+        okmask |= (ok ? 1u : 0u) << k;
+    }
+    // two chunks in flight: chunk c + 2 is requested before the taps of chunk c run and parked behind the taps of chunk c + 1 (one
+    // chunk ahead left the loads ~600 cycles of MFMA to hide an HBM round trip behind)
+    h8 rawA[NPC], rawB[NPC];
+    auto fetch = [&](int c, h8* raw) {
+#pragma unroll
+        for (int k = 0; k < NPC; ++k) raw[k] = *(const h8*)(src + goff[k] + c * 32);          // (pieces past the patch / outside the image: offset 0, never parked / parked as zeros)
+    };
+    auto park = [&](int c, const h8* raw) {                             // normalise + SiLU + round, as k_gn16_apply; zeros outside the image
+        const f32x4 s0 = *(const f32x4*)(sSc + c * 32 + slot * 8), s1 = *(const f32x4*)(sSc + c * 32 + slot * 8 + 4);
+        const f32x4 h0 = *(const f32x4*)(sSh + c * 32 + slot * 8), h1 = *(const f32x4*)(sSh + c * 32 + slot * 8 + 4);
+        char* const dst = smo + (c & 1) * PATCH;
+#pragma unroll
+        for (int k = 0; k < NPC; ++k) {
+            if (loff[k] < 0) continue;
+            float z[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float y = __builtin_fmaf((float)raw[k][e], e < 4 ? s0[e & 3] : s1[e & 3], e < 4 ? h0[e & 3] : h1[e & 3]);
+                z[e] = y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * y));
+            }
+            // the product rounds to fp32 BEFORE the conversion, as in k_gn16_apply (hipcc otherwise merges the two into v_fma_mixlo_f16, which
+            // rounds once: other bits in 1 of 10^4 elements)
+            asm volatile("" : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]), "+v"(z[4]), "+v"(z[5]), "+v"(z[6]), "+v"(z[7]));
+            h8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (vh_e16)z[e];
+            if (!((okmask >> k) & 1u)) o = (h8)(vh_e16)0.0f;
+            *(h8*)(dst + loff[k]) = o;
+        }
+    };
+    fetch(0, rawA);
+    if (nch > 1) fetch(1, rawB);
+    __syncthreads();                                                    // scale / shift table (and the weights) are in LDS
+    park(0, rawA);
+    __syncthreads();
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int rb = wave * 2 * P + r16;                                  // patch row of this lane's pixel of fragment 0 at tap (0, 0): the wave owns output rows 2 wave, 2 wave + 1
+    const char* const wl = sW + (size_t)(r16 < p.N ? r16 : p.N - 1) * K * 2 + kq * 16;      // (rows past Cout repeat the last one: those output channels are never stored)
+    auto taps = [&](int c) {
+        const char* const pa = smo + (c & 1) * PATCH;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ky = t / 3, kx = t - ky * 3;
+            const h8 bn = *(const h8*)(wl + (size_t)(t * p.Cin + c * 32) * 2);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int R = rb + ((i >> 1) + ky) * P + (i & 1) * 16 + kx;
+                const h8 am = *(const h8*)(pa + R * ROWB + ((kq << 4) ^ (((R >> 2) & 1) << 5)));
+                acc[i] = VH16_MFMA_16x16x32(bn, am, acc[i]);
+            }
+        }
+    };
+    // chunk c (even: rawA held it, rawB holds c + 1; odd: the other way round).  The buffer park() writes was read last in chunk c - 1,
+    // which every wave left at the barrier that ends it.
+    for (int c = 0; c < nch; c += 2) {
+        if (c + 2 < nch) fetch(c + 2, rawA);
+        taps(c);
+        if (c + 1 < nch) park(c + 1, rawB);
+        __syncthreads();
+        if (c + 1 >= nch) break;
+        if (c + 3 < nch) fetch(c + 3, rawB);
+        taps(c + 1);
+        if (c + 2 < nch) park(c + 2, rawA);
+        __syncthreads();
+    }
+    // epilogue: acc[i][e] = C[pixel (row 2 wave + (i >> 1), column 16 (i & 1) + r16)][channel 4 kq + e]; fp32 NCHW, clamp (+ de-normalise)
+    if (kq * 4 < p.N) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int y = ty0 + wave * 2 + (i >> 1), x = tx0 + (i & 1) * 16 + r16;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = kq * 4 + e;
+                if (n >= p.N) break;
+                const float v = acc[i][e] + p.bias[n];
+                const float cl = vm_min(vm_max(v, -1.0f), 1.0f);
+                p.out[((int64_t)b * p.N + n) * hw + y * p.Wd + x] = p.out_mode == 1 ? (cl + 1.0f) * 0.5f : cl;
+            }
+        }
+    }
+}
+
+// out = clamp(conv3x3(SiLU(GroupNorm(x))) + bias) in fp32 NCHW (out_mode 2), de-normalised to [0, 1] (out_mode 1): x [B][H][W][Cin] 16-bit
+// channels-last, stats [B][G][2] = (mean, rstd) as varhip_gn_stats_* / varhip_gn_stats_part_f32 leave them, w [Cout][3][3][Cin] 16-bit.
+// Takes maps that tile into 8 x 32 patches with Cin % 32 == 0 and Cout <= 16; anything else returns VARHIP_EINVAL (the caller then runs
+// varhip_gn_apply_* + varhip_conv3x3_nhwc_*, which this call equals bit for bit).
+extern "C" int VH16_FN(gn_silu_conv_out)(const void* x, const float* stats, const float* gamma, const float* beta, const void* w, const float* bias,
+                                           float* out, int B, int H, int W, int Cin, int Cout, int G, int out_mode, varhip_stream_t stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || G <= 0 || !x || !stats || !gamma || !beta || !w || !bias || !out) return VARHIP_EINVAL;
+    if ((H % 8) || (W % 32) || (Cin % 32) || (Cin % G) || Cout > 16 || (out_mode != 1 && out_mode != 2)) return VARHIP_EINVAL;
+    if ((((uintptr_t)x | (uintptr_t)w) & 15) || (int64_t)H * W * Cin * 2 >= (1ll << 31) || (int64_t)B * (H / 8) * (W / 32) >= (1ll << 31)) return VARHIP_EINVAL;
+    constexpr int PATCH = 10 * 34 * 64;
+    const size_t lds = (size_t)2 * PATCH + (((size_t)Cout * 9 * Cin * 2 + 15) & ~(size_t)15) + (size_t)2 * Cin * 4;
+    if (lds > 64 * 1024) return VARHIP_EINVAL;
+    GnConvOP p{(const vh_e16*)x, stats, gamma, beta, (const vh_e16*)w, bias, out, H, W, Cin, Cout, G, out_mode};
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)k_gnconv16o, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); attr_done = true; }
+    const double npix = (double)B * H * W;
+    VhScope scope(VH_FAM_CONV16_SMALL, (hipStream_t)stream, 2.0 * npix * Cout * 9.0 * Cin, 2.0 * npix * Cin + 4.0 * npix * Cout + 18.0 * Cin * Cout);
+    hipLaunchKernelGGL(k_gnconv16o, dim3(B * (H / 8) * (W / 32)), dim3(256), lds, (hipStream_t)stream, p);
+    return vh_launch_status();
+}
+
 }  // namespace VH16_NS

@@ -122,6 +122,7 @@ class DecoderEngine(_VaeOps):
     # here.  The sampling loop does NOT change it: SamplingEngine passes its own precision with every decode_nhwc call, so two VARs
     # sharing one VQVAE, or a VAR in the 16-bit mode next to direct VQVAE calls, never fight over a mode flag.
     precision = 'f32'
+    unfused_tail = False         # tests: run norm_out / conv_out of the 16-bit decoder as two launches
 
     def set_precision(self, precision: str):
         if precision not in PRECISIONS:
@@ -261,7 +262,8 @@ class DecoderEngine(_VaeOps):
         if nblk: self._gn_part = (out, part, nblk)
         return out
 
-    def gn16(self, x, key, B, HW, silu):
+    def gn_stats16(self, x, B, HW):
+        """(mean, rstd) per (sample, group) of a 16-bit channels-last map: from the producing conv's partial sums when it left them, else a pass over x"""
         Cc = x.shape[-1]
         stats = torch.empty((B, 32, 2), dtype=torch.float32, device=x.device)
         pend = self._gn_part
@@ -271,9 +273,27 @@ class DecoderEngine(_VaeOps):
         else:
             scratch = torch.empty(hip.gn_scratch_elems(B, HW, Cc, 32), dtype=torch.float64, device=x.device)
             hip.call('gn_stats_' + self.sfx, x, stats, scratch, B, HW, Cc, 32, 1e-6)
+        return stats
+
+    def gn16(self, x, key, B, HW, silu):
+        stats = self.gn_stats16(x, B, HW)
         out = torch.empty_like(x)
-        hip.call('gn_apply_' + self.sfx, x, stats, self.w[key + '.weight'], self.w[key + '.bias'], out, B, HW, Cc, 32, int(silu))
+        hip.call('gn_apply_' + self.sfx, x, stats, self.w[key + '.weight'], self.w[key + '.bias'], out, B, HW, x.shape[-1], 32, int(silu))
         return out
+
+    def tail16(self, h, B, Hh, Ww, denorm):
+        """norm_out -> swish -> conv_out -> clamp (-> (x + 1) / 2) (basic_vae.py:224-226, vqvae.py:63, var.py:190): one pass over the map
+        (varhip_gn_silu_conv_out_*) where it tiles into 8 x 32 patches, else GroupNorm apply + conv — the same bits either way"""
+        wt = self.w16['decoder.conv_out.weight']
+        Cout, Cin = wt.shape[0], wt.shape[3]
+        if Hh % 8 == 0 and Ww % 32 == 0 and Cin % 32 == 0 and Cout <= 16 and (2 * 22 * 1024 + Cout * 9 * Cin * 2 + 16 + 8 * Cin) <= 64 * 1024 and not self.unfused_tail:
+            stats = self.gn_stats16(h, B, Hh * Ww)
+            out = torch.empty((B, Cout, Hh, Ww), dtype=torch.float32, device=h.device)
+            hip.call('gn_silu_conv_out_' + self.sfx, h, stats, self.w['decoder.norm_out.weight'], self.w['decoder.norm_out.bias'], wt,
+                     self.w['decoder.conv_out.bias'], out, B, Hh, Ww, Cin, Cout, 32, 1 if denorm else 2)
+            return out
+        h = self.gn16(h, 'decoder.norm_out', B, Hh * Ww, True)
+        return self.conv3_16(h, 'decoder.conv_out', B, Hh, Ww, out_mode=1 if denorm else 2)
 
     def resblock16(self, x, pre, B, Hh, Ww):
         HW = Hh * Ww
@@ -348,8 +368,7 @@ class DecoderEngine(_VaeOps):
                 hip.call('upconv_phase_' + self.sfx, h, wp, self.w[key + '.bias'], up, part, B, Hh, Ww, wp.shape[4], wp.shape[1])
                 self._gn_part = (up, part, nblk) if nblk else None
                 h = up
-        h = self.gn16(h, 'decoder.norm_out', B, Hh * Ww, True)
-        return self.conv3_16(h, 'decoder.conv_out', B, Hh, Ww, out_mode=1 if denorm else 2)
+        return self.tail16(h, B, Hh, Ww, denorm)
 
     def decode_nhwc(self, f_hat: torch.Tensor, denorm: bool = True, precision: Optional[str] = None) -> torch.Tensor:
         """[B,P,P,Cvae] channels-last -> [B,3,16P,16P]; denorm=True: in [0,1] (clamp and (x+1)/2 fused into the last conv, what
