@@ -17,6 +17,8 @@ Extra objects in the JSON line:
                steps between barriers, `value`, `ms_per_step`, its own measured dominant kernel with `roofline` and `whole_path`.  The
                headline `value` / `dtype` stay f32.
   modes.bf16   the same for the bfloat16 flavour of that mode.
+               Both carry `two_calls_in_flight`: the same K calls issued alternately on two HIP streams (informational: a serving loop with
+               two requests in flight; every `value` / `ms_per_step` above it is one call at a time on one stream).
   ranks        (N > 1) each rank's own wall time per step, min and max over ranks, and the HIP-event time of the RCCL all-gather.
   roofline     the dominant kernel (largest device time among the single-symbol families, measured in the last warmup step with
                every family timed), re-timed alone with HIP events on the launch stream over the timed region: algorithmic FLOPs / time.
@@ -53,7 +55,17 @@ DOMINANT = {'f32': {'gemm': 'k_dma_gemm<4,4,false,2,false>', 'conv3x3': 'k_dma_g
 DOMINANT['bf16'] = DOMINANT['f16']          # the same kernels compiled with the bf16 MFMA opcodes (namespace vh_bf16 in the symbol)
 
 
-def run_mode(var, dtype, steps, warmup, args, world, step_fn, dist, hip, torch):
+_STREAMS = []
+
+
+def _two_streams(torch):
+    """the same two side streams for every mode (HIP maps streams onto a few hardware queues: a fresh pair per mode can land on one queue)"""
+    if not _STREAMS:
+        _STREAMS.extend([torch.cuda.Stream(), torch.cuda.Stream()])
+    return _STREAMS
+
+
+def run_mode(var, dtype, steps, warmup, args, world, step_fn, dist, hip, torch, in_flight2=False):
     """warm up and time `steps` calls in one precision mode; returns the raw measurements of this rank (dt already MAX-reduced over ranks)"""
     var.set_hip_precision(dtype)
     prepass = None
@@ -88,7 +100,26 @@ def run_mode(var, dtype, steps, warmup, args, world, step_fn, dist, hip, torch):
         from var_amd.multi import rank_stats
         rs = rank_stats(dt, dt_own, gather_ms, steps, img.shape, img.device)
         dt, ranks = rs['dt_max'], rs['ranks']
-    return dict(dt=dt, tt=tt, prepass=prepass, dominant=dominant, ranks=ranks, steps=steps, warmup=warmup, dtype=dtype)
+    res = dict(dt=dt, tt=tt, prepass=prepass, dominant=dominant, ranks=ranks, steps=steps, warmup=warmup, dtype=dtype)
+    if in_flight2:
+        # the same K calls again, issued alternately on two HIP streams (a call's buffers are per stream): two calls in flight, so that the
+        # latency-bound small scales and ragged last rounds of one call run beside the other's full-chip kernels.  Same barriers, same clock.
+        streams = _two_streams(torch)
+        for i in range(2):
+            with torch.cuda.stream(streams[i]): step_fn(500 + i, None)
+        dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            with torch.cuda.stream(streams[i % 2]): img = step_fn(1000 + i, None)
+        torch.cuda.synchronize()
+        dist.barrier()
+        dt2 = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt2], dtype=torch.float64, device=img.device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt2 = float(t.item())
+        res['dt_in_flight2'] = dt2
+    return res
 
 
 def describe_mode(m, args, world, var, pns):
@@ -204,7 +235,7 @@ def main():
     others = {}
     if args.dtype == 'f32' and not args.no_modes:
         for dt16 in ('f16', 'bf16'):
-            others[dt16] = run_mode(var, dt16, max(10, args.steps), 2, args, world, step, dist, hip, torch)
+            others[dt16] = run_mode(var, dt16, max(10, args.steps), 2, args, world, step, dist, hip, torch, in_flight2=True)
 
     if rank == 0:
         precision = {'f32': 'fp32 parity mode', 'f16': 'fp16 GEMM / conv operands, activations and KV cache, fp32 accumulate and statistics',
@@ -233,6 +264,13 @@ def main():
                                                  'roofline': roof2, 'whole_path': whole2, **extra2}
             if other['ranks'] is not None:
                 out['modes'][dt16]['ranks'] = other['ranks']
+            if 'dt_in_flight2' in other:
+                v2 = B_total * other['steps'] / other['dt_in_flight2']
+                out['modes'][dt16]['two_calls_in_flight'] = {
+                    'value': round(v2, 3), 'unit': 'images/sec', 'ms_per_step': round(other['dt_in_flight2'] / other['steps'] * 1e3, 3), 'steps': other['steps'],
+                    'speedup_vs_one_call_at_a_time': round(v2 / ips2, 3),
+                    'frac_of_mfma_peak_reference_flops': round(whole2['frac_of_mfma_peak_reference_flops'] * v2 / ips2, 4),
+                    'how': 'the same calls issued alternately on two HIP streams of one process and model (per-stream workspaces); `value` above is one call at a time'}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.depth, pns)
         print(json.dumps(out), flush=True)

@@ -43,6 +43,8 @@ def test_bench_line_has_the_contract_keys():
         r16 = m['roofline']
         assert r16['peak'] == 2500.0 and r16['family'] in ('gemm16', 'conv16h', 'attn16') and 0 < r16['frac'] < 1 and r16['launches'] > 0
         assert m['whole_path']['peak_tflops'] == 2500.0 and set(m['whole_path']['mfma_time_weighted']['families']) >= {'gemm16_small', 'gemm_small'}
+        t2 = m['two_calls_in_flight']                       # informational: the same calls on two alternating streams; `value` stays one call at a time
+        assert t2['steps'] == m['steps'] and t2['value'] > 0 and abs(t2['speedup_vs_one_call_at_a_time'] - t2['value'] / m['value']) < 1e-2
 
 
 def test_bench_line_f16_headline_and_no_modes():

@@ -561,7 +561,7 @@ class SamplingEngine:
     def __init__(self, var):
         self.var = var
         self._sig = None
-        self._ws: Dict[int, dict] = {}
+        self._ws: Dict[tuple, dict] = {}            # (batch size, HIP stream) -> buffers of a call
         self.precision = 'f32'              # 'f16': the 16-bit throughput mode of the transformer (include/var_hip.h "f16"), explicitly selected
         self.dec = var.vae_proxy[0]._decoder_engine()       # the VQVAE's own engine: one packed copy of the decoder weights, one place to invalidate
         self.last_trace: Optional[dict] = None
@@ -647,7 +647,11 @@ class SamplingEngine:
 
     # -- workspaces --------------------------------------------------------------------------------------------------
     def workspace(self, B: int):
-        ws = self._ws.get(B)
+        """buffers of one call (residual stream, GEMM operands, KV caches ...), cached per (batch size, HIP stream): calls issued on
+        DIFFERENT streams may be in flight together — each owns its buffers, everything else a call allocates comes from torch's
+        stream-ordered allocator — and a call's latency-bound small scales then run beside another call's decoder"""
+        sid = int(torch.cuda.current_stream().cuda_stream)
+        ws = self._ws.get((B, sid))
         dev = self.var.pos_start.device
         if ws is not None and ws['dev'] == dev:
             return ws
@@ -664,7 +668,8 @@ class SamplingEngine:
                   kc=[torch.zeros(2 * B, H, L, 64, dtype=act, device=dev) for _ in range(var.depth)],
                   vc=[torch.zeros(2 * B, H, L, 64, dtype=act, device=dev) for _ in range(var.depth)],
                   f_hat=e(B, P, P, Cv), up=e(B, P, P, Cv), pooled=e(B * lmax, Cv))
-        self._ws = {B: ws}          # one batch size resident at a time
+        self._ws = {k: v for k, v in self._ws.items() if k[1] != sid}          # one batch size resident at a time (per stream)
+        self._ws[(B, sid)] = ws
         return ws
 
     def gemm(self, A, W, bias, out, M, epi=EPI_NONE, resid=None, gamma=None, ldg=0, rpg=1):
@@ -897,7 +902,8 @@ class SamplingEngine:
             raise ValueError(f'labels must lie in [0, {var.num_classes}]')
         lmax = max(p * p for p in var.patch_nums)
         hid = var.blocks[0].ffn.fc1.weight.shape[0]
-        ws = self._ws_tf.get(R) if hasattr(self, '_ws_tf') else None
+        sid = int(torch.cuda.current_stream().cuda_stream)
+        ws = self._ws_tf.get((R, sid)) if hasattr(self, '_ws_tf') else None
         if ws is None or ws['dev'] != dev:
             e = lambda *s, dt=torch.float32: torch.empty(*s, dtype=dt, device=dev)
             act = DT16.get(self.precision, torch.float32)
@@ -908,7 +914,8 @@ class SamplingEngine:
                       shared=e(R, 6 * C) if var.shared_aln else None,
                       kc=[torch.zeros(R, H, L, 64, dtype=act, device=dev) for _ in range(var.depth)],
                       vc=[torch.zeros(R, H, L, 64, dtype=act, device=dev) for _ in range(var.depth)])
-            self._ws_tf = {R: ws}
+            self._ws_tf = {k: v for k, v in getattr(self, '_ws_tf', {}).items() if k[1] != sid}
+            self._ws_tf[(R, sid)] = ws
         lab = label_B.to(dev).long().contiguous()
         hip.call('lvl_pos_f32', w['lvl_embed'], w['lvl_1L'], w['pos_1LC'], ws['lvl_pos'], L, C)
         hip.call('first_map_f32', w['class_emb'], lab, var.num_classes, w['pos_start'], ws['lvl_pos'], ws['cond'], ws['x'], R, C, var.first_l)
