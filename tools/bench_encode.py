@@ -33,7 +33,7 @@ def main():
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--depth', type=int, default=16)
-    ap.add_argument('--dtype', default='f32', choices=['f32', 'f16'])
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'f16', 'bf16'])
     a = ap.parse_args()
     torch.cuda.set_device(0)
     dev = torch.device('cuda', 0)
@@ -91,7 +91,7 @@ def main():
     eng = var.engine()
     fwd_flops = eng.flops_per_image() / 2.0 * B                 # teacher forcing: B rows (no CFG pair)
     enc_flops = enc_flops_per_image(vae) * B
-    peak_fwd = PEAK16 if a.dtype == 'f16' else PEAK32
+    peak_fwd = PEAK16 if a.dtype != 'f32' else PEAK32
     out = {'workload': f'encode + teacher-forced likelihood, VAR-d{a.depth}, B={B} images 256x256, random-init (detinit seed 0)', 'dtype': a.dtype,
            'ms': {k: round(v, 3) for k, v in med.items()}, 'ms_total': round(sum(med.values()), 3), 'images_per_sec': round(B / sum(med.values()) * 1e3, 1),
            'encoder': {'gflop_per_image': round(enc_flops / B / 1e9, 1), 'tflops': round(enc_flops / med['img_to_post (encoder + quant_conv)'] / 1e9, 1),

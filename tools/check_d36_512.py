@@ -15,7 +15,7 @@ from var_amd.detinit import fill_module_device_
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=8)
-ap.add_argument('--dtype', default='f32', choices=['f32', 'f16'])
+ap.add_argument('--dtype', default='f32', choices=['f32', 'f16', 'bf16'])
 ap.add_argument('--calls', type=int, default=2)
 args = ap.parse_args()
 B = args.batch
@@ -37,7 +37,7 @@ assert img.shape == (B, 3, 512, 512) and bool(torch.isfinite(img).all()) and flo
 eng = var.engine()
 flops_img = eng.flops_per_image() + eng.dec.flops_per_image_reference(pns[-1])
 dt = min(times[1:])
-peak = 2500.0 if args.dtype == 'f16' else 157.3
+peak = 2500.0 if args.dtype != 'f32' else 157.3
 print(json.dumps({'config': 'VAR-d36 512x512 (patch_nums up to 32, L=2240), shared AdaLN, CFG=1.5, top_k=900, top_p=0.96, 1 GPU', 'dtype': args.dtype, 'batch': B,
                   'parameters_B': round(nparam / 1e9, 2), 'images_per_sec': round(B / dt, 3), 'sec_per_call': round(dt, 3), 'first_call_sec': round(times[0], 2),
                   'tflop_per_image': round(flops_img / 1e12, 2), 'tflops': round(B / dt * flops_img / 1e12, 1), 'frac_of_mfma_peak': round(B / dt * flops_img / 1e12 / peak, 4),

@@ -19,7 +19,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser()
-ap.add_argument('--dtype', default='f32', choices=['f32', 'f16'])
+ap.add_argument('--dtype', default='f32', choices=['f32', 'f16', 'bf16'])
 ap.add_argument('--batch', type=int, default=64)
 ap.add_argument('--depth', type=int, default=16)
 ap.add_argument('--reps', type=int, default=5)
@@ -45,7 +45,7 @@ for r in range(args.reps):
     var.autoregressive_infer_cfg(B, labels, g_seed=1 + r, cfg=1.5, top_k=900, top_p=0.96)
     runs.append(eng.last_scale_ms)
 C, depth, V = var.C, var.depth, var.V
-wbytes = depth * 12 * C * C * (2 if args.dtype == 'f16' else 4) + C * V * (2 if args.dtype == 'f16' else 4)     # block + head weights read per scale
+wbytes = depth * 12 * C * C * (2 if args.dtype != 'f32' else 4) + C * V * (2 if args.dtype != 'f32' else 4)     # block + head weights read per scale
 rows, cur = [], 0
 for si, pn in enumerate(pns):
     l = pn * pn; cur += l
