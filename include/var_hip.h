@@ -200,6 +200,13 @@ int varhip_gn_stats_f32(const float* x, float* stats, double* scratch, int B, in
 int varhip_gn_apply_f32(const float* x, const float* stats, const float* gamma, const float* beta, float* out,
                         int B, int HW, int C, int G, int silu, varhip_stream_t stream);
 
+/* the decoder's tail in one pass (basic_vae.py:224-226 norm_out -> swish -> conv_out, the callers' clamp vqvae.py:63 and (x + 1) / 2 var.py:190):
+ * out = clamp(conv3x3(SiLU(GroupNorm(x))) + bias, -1, 1) as fp32 NCHW (out_mode 2) or de-normalised to [0, 1] (out_mode 1); stats [B][G][2] = (mean, rstd).
+ * Bit-identical to varhip_gn_apply_f32 (silu = 1) followed by varhip_conv3x3_nhwc_f32 (same out_mode): same operations per element, same
+ * chunk / tap / channel summation order.  Shapes it does not take (H % 8, W % 32, Cin % 32, Cout > 4): VARHIP_EINVAL. */
+int varhip_gn_silu_conv_out_f32(const float* x, const float* stats, const float* gamma, const float* beta, const float* w, const float* bias,
+                                float* out, int B, int H, int W, int Cin, int Cout, int G, int out_mode, varhip_stream_t stream);
+
 /* out[r][:] = softmax(x[r][:] * scale), rows of length n   (basic_vae.py:83-84: bmm(...).mul_(w_ratio); softmax(dim=2)) */
 int varhip_softmax_rows_f32(const float* x, float* out, int64_t rows, int n, float scale, varhip_stream_t stream);
 

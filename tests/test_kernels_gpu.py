@@ -654,3 +654,48 @@ def test_vm_exp_matches_cpu_bit_for_bit():
     y = np.zeros_like(v)
     (g,), (w,) = both('silu_f32', [v, y, v.size], [1])
     check('silu sweep', g, w)
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout,omode', [(2, 8, 32, 32, 3, 1), (1, 64, 64, 160, 3, 2), (3, 16, 96, 64, 3, 1), (1, 24, 32, 96, 4, 2), (2, 16, 32, 64, 1, 1), (2, 256, 256, 160, 3, 1)])
+def test_gn_silu_conv_out_f32_fused_equals_two_launches(B, H, W, Cin, Cout, omode):
+    """the fp32 decoder's tail (norm_out -> swish -> conv_out -> clamp, basic_vae.py:224-226) in one pass (one output pixel per thread, the
+    convolution as per-thread fma chains in the chunk / tap / channel order) against varhip_gn_apply_f32 + varhip_conv3x3_nhwc_f32: identical
+    bits — the image border and every patch edge included; the conv itself is pinned against the oracle by test_conv3x3_exact"""
+    from var_amd import hip
+    g = torch.Generator().manual_seed(H * 7 + W + Cin + Cout)
+    x = (torch.randn(B, H, W, Cin, generator=g) * 1.3 + 0.2).cuda()
+    w = (torch.randn(Cout, 3, 3, Cin, generator=g) * (2.0 / (9 * Cin) ** 0.5)).cuda()
+    bias = (torch.randn(Cout, generator=g) * 0.1).cuda()
+    gamma, beta = (torch.randn(Cin, generator=g) * 0.2 + 1.0).cuda(), (torch.randn(Cin, generator=g) * 0.2).cuda()
+    stats = torch.empty(B, 32, 2, dtype=torch.float32, device='cuda')
+    scratch = torch.empty(hip.gn_scratch_elems(B, H * W, Cin, 32), dtype=torch.float64, device='cuda')
+    hip.call('gn_stats_f32', x, stats, scratch, B, H * W, Cin, 32, 1e-6)
+    fused = torch.full((B, Cout, H, W), float('nan'), dtype=torch.float32, device='cuda')
+    hip.call('gn_silu_conv_out_f32', x, stats, gamma, beta, w, bias, fused, B, H, W, Cin, Cout, 32, omode)
+    xn = torch.empty_like(x)
+    hip.call('gn_apply_f32', x, stats, gamma, beta, xn, B, H * W, Cin, 32, 1)
+    two = torch.empty_like(fused)
+    hip.call('conv3x3_nhwc_f32', xn, w, bias, None, two, B, H, W, Cin, Cout, 0, omode)
+    assert torch.equal(fused, two), f'fused tail differs from the two launches in {int((fused != two).sum())} elements, max {float((fused - two).abs().max()):.3e}'
+    if B * H * W <= 70000:
+        ref = torch.nn.functional.conv2d(xn.double().cpu().permute(0, 3, 1, 2), w.double().cpu().permute(0, 3, 1, 2), bias.double().cpu(), padding=1).clamp(-1, 1)
+        if omode == 1: ref = (ref + 1) * 0.5
+        assert float((fused.double().cpu() - ref).abs().max()) <= 1e-5
+    with pytest.raises(Exception):
+        hip.call('gn_silu_conv_out_f32', x, stats, gamma, beta, w, bias, fused, B, H, W - 1, Cin, Cout, 32, omode)
+
+
+def test_decoder_f32_fused_tail_equals_unfused():
+    """VQVAE.fhat_to_img (d16-size decoder, 256x256, B=2): the one-pass tail and the two-launch tail give the same image bit for bit"""
+    from tests.test_f16_gpu import _models
+    z, meta = util.load_case('d16_full')
+    vae, var = _models(meta)
+    g = torch.Generator().manual_seed(4)
+    f_hat = (torch.randn(2, 32, 16, 16, generator=g) * 1.5).cuda()
+    eng = vae._decoder_engine()
+    with torch.inference_mode():
+        a = vae.fhat_to_img(f_hat).clone()
+        eng.unfused_tail = True
+        try: b = vae.fhat_to_img(f_hat).clone()
+        finally: eng.unfused_tail = False
+    assert torch.equal(a, b) and torch.isfinite(a).all() and float(a.abs().max()) <= 1.0

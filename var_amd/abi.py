@@ -68,6 +68,11 @@ SIGNATURES_F16 = {
     'cast_f16_to_f32':   [P, P, L],
 }
 
+# entry points of the HIP library that have no oracle twin of their own (they are pinned against other entry points bit for bit)
+SIGNATURES_HIP_ONLY = {
+    'gn_silu_conv_out_f32': [P, P, P, P, P, P, P, I, I, I, I, I, I, I],
+}
+
 # ... and with bfloat16 storage: one entry point per _f16 entry point, same arguments (include/var_hip.h, "bf16")
 SIGNATURES_BF16 = {k.replace('_f16out', '_bf16out').replace('_to_f16', '_to_bf16').replace('cast_f16_', 'cast_bf16_').replace('_f16', '_bf16'): v
                    for k, v in SIGNATURES_F16.items()}
@@ -83,6 +88,7 @@ def bind(lib, prefix: str, with_stream: bool):
     if with_stream:                      # the HIP library also carries the 16-bit mode
         table.update(SIGNATURES_F16)
         table.update(SIGNATURES_BF16)
+        table.update(SIGNATURES_HIP_ONLY)
     for name, args in table.items():
         fn = getattr(lib, prefix + name)
         fn.argtypes = list(args) + ([P] if with_stream else [])

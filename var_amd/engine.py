@@ -122,7 +122,7 @@ class DecoderEngine(_VaeOps):
     # here.  The sampling loop does NOT change it: SamplingEngine passes its own precision with every decode_nhwc call, so two VARs
     # sharing one VQVAE, or a VAR in the 16-bit mode next to direct VQVAE calls, never fight over a mode flag.
     precision = 'f32'
-    unfused_tail = False         # tests: run norm_out / conv_out of the 16-bit decoder as two launches
+    unfused_tail = False         # tests: run norm_out / conv_out of the decoder as two launches
 
     def set_precision(self, precision: str):
         if precision not in PRECISIONS:
@@ -185,6 +185,33 @@ class DecoderEngine(_VaeOps):
         out = torch.empty_like(x)
         hip.call('gn_apply_f32', x, stats, self.w[key + '.weight'], self.w[key + '.bias'], out, B, HW, Cc, 32, int(silu))
         return out
+
+    def gn_stats(self, x, B, HW):
+        """(mean, rstd) per (sample, group): from the producing conv's partial sums when it left them, else a pass over x"""
+        Cc = x.shape[-1]
+        stats = torch.empty((B, 32, 2), dtype=torch.float32, device=x.device)
+        pend = self._gn_part
+        self._gn_part = None
+        if pend is not None and pend[0].data_ptr() == x.data_ptr() and pend[0].numel() == x.numel() and tuple(pend[1].shape) == (B, pend[2], Cc, 2):
+            hip.call('gn_stats_part_f32', pend[1], stats, B, pend[2], HW, Cc, 32, 1e-6)
+        else:
+            scratch = torch.empty(hip.gn_scratch_elems(B, HW, Cc, 32), dtype=torch.float64, device=x.device)
+            hip.call('gn_stats_f32', x, stats, scratch, B, HW, Cc, 32, 1e-6)
+        return stats
+
+    def tail(self, h, B, Hh, Ww, denorm):
+        """norm_out -> swish -> conv_out -> clamp (-> (x + 1) / 2) (basic_vae.py:224-226, vqvae.py:63, var.py:190): one pass over the map
+        (varhip_gn_silu_conv_out_f32) where it tiles into 8 x 32 patches, else GroupNorm apply + conv — the same bits either way"""
+        wt = self.w['decoder.conv_out.weight']
+        Cout, Cin = wt.shape[0], wt.shape[3]
+        if Hh % 8 == 0 and Ww % 32 == 0 and Cin % 32 == 0 and Cout <= 4 and (10 * 34 * 36 + 4 * Cin) * 4 <= 64 * 1024 and not self.unfused_tail:
+            stats = self.gn_stats(h, B, Hh * Ww)
+            out = torch.empty((B, Cout, Hh, Ww), dtype=torch.float32, device=h.device)
+            hip.call('gn_silu_conv_out_f32', h, stats, self.w['decoder.norm_out.weight'], self.w['decoder.norm_out.bias'], wt,
+                     self.w['decoder.conv_out.bias'], out, B, Hh, Ww, Cin, Cout, 32, 1 if denorm else 2)
+            return out
+        h = self.gn(h, 'decoder.norm_out', B, Hh * Ww, True)
+        return self.conv3(h, 'decoder.conv_out', B, Hh, Ww, out_mode=1 if denorm else 2)
 
     def lin(self, x2d, key, resid=None):
         wt = self.w[key + '.weight']
@@ -404,8 +431,7 @@ class DecoderEngine(_VaeOps):
                 else:
                     hip.call('upconv_phase_f32', h, wp, self.w[key + '.bias'], up, B, Hh, Ww, wp.shape[4], wp.shape[1])
                 h = up
-        h = self.gn(h, 'decoder.norm_out', B, Hh * Ww, True)
-        return self.conv3(h, 'decoder.conv_out', B, Hh, Ww, out_mode=1 if denorm else 2)
+        return self.tail(h, B, Hh, Ww, denorm)
 
 
 class QuantizerEngine:
