@@ -26,7 +26,7 @@ Extra objects in the JSON line:
                in a folded 4-tap form), both as a fraction of the MFMA peak of the mode; mfma_time_weighted: FLOPs / time summed over
                every GEMM / conv / attention launch of the profiled warmup step.
   cpu_baseline the CPU oracle (oracle/, a scalar C port of the reference algorithm; kind "port") timed on this box's host
-               cores on a bounded sample: four images through all 10 scales + decode (rank 0, N=1 only).
+               cores on a bounded sample: eight images through all 10 scales + decode (rank 0, N=1 only).
 """
 import argparse
 import contextlib
@@ -279,7 +279,7 @@ def main():
 
 
 def cpu_baseline(depth, pns):
-    """the CPU oracle on a bounded sample — FOUR images (about 13 s), all scales + decode — OpenMP over this box's host cores"""
+    """the CPU oracle on a bounded sample — EIGHT images (about 10 s on 16 cores), all scales + decode — OpenMP over this box's host cores"""
     import numpy as np
     import torch
     from oracle.var_oracle import OracleVAR
@@ -297,14 +297,15 @@ def cpu_baseline(depth, pns):
     so = ctypes.CDLL(os.path.join(ROOT, 'oracle', 'libvar_oracle.so'))
     threads = int(so.varref_set_threads(int(os.environ.get('OMP_NUM_THREADS', min(avail, 16)))))   # a 1-GPU box's CPU share is 16 cores
     g = torch.Generator().manual_seed(0)
-    nimg = 4
+    nimg = 8
     noise = [torch.empty(nimg * pn * pn, 4096).exponential_(1, generator=g).numpy() for pn in pns]
     t0 = time.perf_counter()
-    r = orc.run([7, 14, 21, 28][:nimg], noise, 1.5, 900, 0.96)
+    labels = [7 * (i + 1) for i in range(nimg)]
+    r = orc.run(labels, noise, 1.5, 900, 0.96)
     dt = time.perf_counter() - t0
     assert np.isfinite(r['img']).all()
     return {'value': round(nimg / dt, 4), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
-            'sample': f'{nimg} images (labels 7, 14, 21, 28), all 10 scales + VQVAE decode, oracle/var_oracle.c via OpenMP: {dt:.1f} s'}
+            'sample': f'{nimg} images (labels 7, 14, ..., {7 * nimg}), all 10 scales + VQVAE decode, oracle/var_oracle.c via OpenMP: {dt:.1f} s'}
 
 
 if __name__ == '__main__':

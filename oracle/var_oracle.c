@@ -68,36 +68,83 @@ int varref_set_threads(int n) { (void)n; return 1; }
  * GEMM  out = epi(A . W^T + bias)        reference: F.linear at basic_var.py:93,119,52,147,170; var.py:124;
  * 1x1 convs and bmm's of basic_vae.py:53,69,71,83,89.   Wt is W transposed to [K][N] (so the n loop vectorises;
  * each out[m][n] is still its own k-ascending fma chain). */
+#include <immintrin.h>
+/* register-blocked inner kernel: MR rows x 16 columns of out held in ymm registers over the whole k loop.  Every element is still its own
+ * k-ascending chain acc = fma(a[m][k], w[k][n], acc) from 0 (one _mm256_fmadd_ps lane each) — the blocking only changes how often a
+ * weight row is re-read (once per MR rows instead of once per row), not one bit of any result. */
+#define GEMM_MR 6
+static inline void gemm_micro_6x16(const float* const a[GEMM_MR], const float* wt, int64_t ldwt, int K, float acc[GEMM_MR][16]) {
+    __m256 c[GEMM_MR][2];
+    for (int r = 0; r < GEMM_MR; ++r) { c[r][0] = _mm256_setzero_ps(); c[r][1] = _mm256_setzero_ps(); }
+    for (int k = 0; k < K; ++k) {
+        const __m256 b0 = _mm256_loadu_ps(wt + (int64_t)k * ldwt), b1 = _mm256_loadu_ps(wt + (int64_t)k * ldwt + 8);
+        for (int r = 0; r < GEMM_MR; ++r) {
+            const __m256 av = _mm256_broadcast_ss(a[r] + k);
+            c[r][0] = _mm256_fmadd_ps(av, b0, c[r][0]);
+            c[r][1] = _mm256_fmadd_ps(av, b1, c[r][1]);
+        }
+    }
+    for (int r = 0; r < GEMM_MR; ++r) { _mm256_storeu_ps(acc[r], c[r][0]); _mm256_storeu_ps(acc[r] + 8, c[r][1]); }
+}
+
 static void gemm_kn_core(const float* A, int64_t lda, const float* Wt, int64_t ldwt, const float* bias, float* out, int64_t ldo,
                          int M, int N, int K, int epi, const float* resid, int64_t ldr, const float* gamma, int64_t ldg,
                          int rows_per_group, int bias_per_row) {
-    const int NB = 256;
-    int nblk = (N + NB - 1) / NB;
-#pragma omp parallel for collapse(2) schedule(static)
-    for (int m = 0; m < M; ++m) {
-        for (int nb = 0; nb < nblk; ++nb) {
-            int n0 = nb * NB, n1 = n0 + NB < N ? n0 + NB : N, w = n1 - n0;
-            float acc[256];
-            for (int j = 0; j < w; ++j) acc[j] = 0.0f;
-            const float* a = A + (int64_t)m * lda;
-            for (int k = 0; k < K; ++k) {
-                float av = a[k];
-                const float* wr = Wt + (int64_t)k * ldwt + n0;
-#pragma omp simd
-                for (int j = 0; j < w; ++j) acc[j] = vm_fma(av, wr[j], acc[j]);
+    const int NB = 16;
+    const int nblk = (N + NB - 1) / NB, mblk = (M + GEMM_MR - 1) / GEMM_MR;
+    /* one task = one 16-column panel of Wt, copied once into a contiguous K x 16 buffer (its rows lie N floats apart: at N = 3072 every
+     * row of the panel lands in the same cache sets) and used for every row block; with few panels (N < 512) the (panel, row block) pairs
+     * are the tasks and the panel is read in place */
+    const int pack = nblk >= 32;
+#pragma omp parallel
+    {
+        float* panel = pack ? (float*)aligned_alloc(64, sizeof(float) * (size_t)K * NB) : NULL;
+        const int64_t ntask = pack ? nblk : (int64_t)nblk * mblk;
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t task = 0; task < ntask; ++task) {
+            const int nb = pack ? (int)task : (int)(task / mblk), mb_lo = pack ? 0 : (int)(task % mblk), mb_hi = pack ? mblk : mb_lo + 1;
+            const int n0 = nb * NB, w = (n0 + NB < N ? n0 + NB : N) - n0;
+            const float* wp = Wt + n0; int64_t ldp = ldwt;
+            if (pack && w == NB) {
+                for (int k = 0; k < K; ++k) { _mm256_store_ps(panel + (int64_t)k * NB, _mm256_loadu_ps(Wt + (int64_t)k * ldwt + n0));
+                                              _mm256_store_ps(panel + (int64_t)k * NB + 8, _mm256_loadu_ps(Wt + (int64_t)k * ldwt + n0 + 8)); }
+                wp = panel; ldp = NB;
             }
-            float* o = out + (int64_t)m * ldo + n0;
-            for (int j = 0; j < w; ++j) {
-                float v = acc[j];
-                if (bias) v = v + (bias_per_row ? bias[m] : bias[n0 + j]);
-                if (epi == EPI_GELU) v = vm_gelu_tanh(v);
-                else if (epi == EPI_RESID) {
-                    if (gamma) v = v * gamma[(int64_t)(m / rows_per_group) * ldg + n0 + j];
-                    v = resid[(int64_t)m * ldr + n0 + j] + v;
+            for (int mb = mb_lo; mb < mb_hi; ++mb) {
+                const int m0 = mb * GEMM_MR, mr = (m0 + GEMM_MR < M ? m0 + GEMM_MR : M) - m0;
+                float acc[GEMM_MR][16];
+                if (w == NB) {
+                    const float* a[GEMM_MR];
+                    for (int r = 0; r < GEMM_MR; ++r) a[r] = A + (int64_t)(m0 + (r < mr ? r : 0)) * lda;      /* (rows past M: a repeat, discarded) */
+                    gemm_micro_6x16(a, wp, ldp, K, acc);
+                } else {                                             /* ragged last column block: the plain loops, same chains */
+                    for (int r = 0; r < mr; ++r) {
+                        for (int j = 0; j < w; ++j) acc[r][j] = 0.0f;
+                        const float* a = A + (int64_t)(m0 + r) * lda;
+                        for (int k = 0; k < K; ++k) {
+                            const float av = a[k];
+                            const float* wr = Wt + (int64_t)k * ldwt + n0;
+                            for (int j = 0; j < w; ++j) acc[r][j] = vm_fma(av, wr[j], acc[r][j]);
+                        }
+                    }
                 }
-                o[j] = v;
+                for (int r = 0; r < mr; ++r) {
+                    const int m = m0 + r;
+                    float* o = out + (int64_t)m * ldo + n0;
+                    for (int j = 0; j < w; ++j) {
+                        float v = acc[r][j];
+                        if (bias) v = v + (bias_per_row ? bias[m] : bias[n0 + j]);
+                        if (epi == EPI_GELU) v = vm_gelu_tanh(v);
+                        else if (epi == EPI_RESID) {
+                            if (gamma) v = v * gamma[(int64_t)(m / rows_per_group) * ldg + n0 + j];
+                            v = resid[(int64_t)m * ldr + n0 + j] + v;
+                        }
+                        o[j] = v;
+                    }
+                }
             }
         }
+        free(panel);
     }
 }
 
@@ -605,6 +652,53 @@ int varref_first_map_f32(const float* class_emb, const int64_t* labels, int num_
 
 /* Conv2d k=3 s=1 p=1 in channels-last form (basic_vae.py:25,48,51,180,208; vqvae.py:49).  wt is the weight
  * re-laid as [3][3][Cin][Cout] so the co loop vectorises; each out element is one (ky,kx,ci)-ascending fma chain. */
+/* taps and source pixel of output pixel (y, x): returns 0 when tap (ky, kx) falls into the zero padding */
+static inline int conv_src(int up2, int H, int W, int Hi, int Wi, int y, int x, int ky, int kx, int* sy, int* sx) {
+    const int yy = up2 == 3 ? 2 * y + ky : y + ky - 1, xx = up2 == 3 ? 2 * x + kx : x + kx - 1;
+    if (yy < 0 || yy >= (up2 == 3 ? Hi : H) || xx < 0 || xx >= (up2 == 3 ? Wi : W)) return 0;
+    *sy = up2 == 1 ? yy >> 1 : yy; *sx = up2 == 1 ? xx >> 1 : xx;                    /* nearest 2x: src = dst // 2 */
+    return 1;
+}
+static inline void conv_store(const float* acc, int co0, int co1, const float* bias, const float* resid, float* out,
+                              int b, int y, int x, int H, int W, int Cout, int out_mode) {
+    for (int co = co0; co < co1; ++co) {
+        float v = acc[co - co0] + bias[co];
+        if (resid) v = v + resid[(((int64_t)b * H + y) * W + x) * Cout + co];
+        if (out_mode != 0) {
+            v = vm_min(vm_max(v, -1.0f), 1.0f);                                   /* vqvae.py:63 clamp_(-1,1) */
+            out[(((int64_t)b * Cout + co) * H + y) * W + x] = out_mode == 1 ? (v + 1.0f) * 0.5f : v;   /* var.py:190 add_(1).mul_(0.5) */
+        } else out[(((int64_t)b * H + y) * W + x) * Cout + co] = v;
+    }
+}
+/* one output pixel, output channels [co0, co1): the plain loops */
+static void conv_pixel(const float* in, const float* wt, float* acc, int b, int y, int x, int H, int W, int Hi, int Wi, int Cin, int Cout,
+                       int up2, int co0, int co1) {
+    for (int co = co0; co < co1; ++co) acc[co - co0] = 0.0f;
+    /* summation order of the contract (include/var_hip.h): channel chunks of 32 outermost, then the 9 taps, then the
+     * channels of the chunk — all taps of a chunk touch the same few cache lines, which is what keeps the GPU kernel's
+     * operand re-reads inside the L2 */
+    for (int c0 = 0; c0 < Cin; c0 += 32) {
+        const int c1 = c0 + 32 < Cin ? c0 + 32 : Cin;
+        for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx) {
+                int sy, sx;
+                if (!conv_src(up2, H, W, Hi, Wi, y, x, ky, kx, &sy, &sx)) continue;
+                const float* ip = in + (((int64_t)b * Hi + sy) * Wi + sx) * Cin;
+                const float* wp = wt + ((int64_t)(ky * 3 + kx) * Cin) * Cout;
+                for (int ci = c0; ci < c1; ++ci) {
+                    const float a = ip[ci];
+                    const float* wr = wp + (int64_t)ci * Cout;
+#pragma omp simd
+                    for (int co = co0; co < co1; ++co) acc[co - co0] = vm_fma(a, wr[co], acc[co - co0]);
+                }
+            }
+    }
+}
+
+/* Conv2d k=3 s=1 p=1 in channels-last form (basic_vae.py:25,48,51,180,208; vqvae.py:49).  wt is the weight
+ * re-laid as [3][3][Cin][Cout] so the co loop vectorises; each out element is one (chunk, ky, kx, ci)-ascending fma chain.
+ * Interior pixels (every tap's column inside the image) are computed six at a time x sixteen output channels in registers — the same
+ * chains, each weight row read once per six pixels instead of once per pixel; the first and last pixel of a row take the plain loops. */
 static void conv3x3_core(const float* in, const float* wt, const float* bias, const float* resid, float* out,
                          int B, int H, int W, int Cin, int Cout, int up2, int out_mode) {
     /* up2: 0 plain, 1 input read through a nearest 2x upsampling, 3 stride-2 over an input padded (0,1,0,1) (Downsample2x) */
@@ -612,37 +706,51 @@ static void conv3x3_core(const float* in, const float* wt, const float* bias, co
 #pragma omp parallel for collapse(2) schedule(static)
     for (int b = 0; b < B; ++b)
         for (int y = 0; y < H; ++y) {
-            float* acc = (float*)malloc(sizeof(float) * Cout);
-            for (int x = 0; x < W; ++x) {
-                for (int co = 0; co < Cout; ++co) acc[co] = 0.0f;
-                /* summation order of the contract (include/var_hip.h): channel chunks of 32 outermost, then the 9 taps, then the
-                 * channels of the chunk — all taps of a chunk touch the same few cache lines, which is what keeps the GPU kernel's
-                 * operand re-reads inside the L2 */
-                for (int c0 = 0; c0 < Cin; c0 += 32) {
-                    int c1 = c0 + 32 < Cin ? c0 + 32 : Cin;
-                    for (int ky = 0; ky < 3; ++ky) {
-                        int yy = up2 == 3 ? 2 * y + ky : y + ky - 1; if (yy < 0 || yy >= (up2 == 3 ? Hi : H)) continue;
-                        for (int kx = 0; kx < 3; ++kx) {
-                            int xx = up2 == 3 ? 2 * x + kx : x + kx - 1; if (xx < 0 || xx >= (up2 == 3 ? Wi : W)) continue;
-                            int sy = up2 == 1 ? yy >> 1 : yy, sx = up2 == 1 ? xx >> 1 : xx;     /* nearest 2x: src = dst // 2 */
-                            const float* ip = in + (((int64_t)b * Hi + sy) * Wi + sx) * Cin;
-                            const float* wp = wt + ((int64_t)(ky * 3 + kx) * Cin) * Cout;
-                            for (int ci = c0; ci < c1; ++ci) {
-                                float a = ip[ci];
-                                const float* wr = wp + (int64_t)ci * Cout;
-#pragma omp simd
-                                for (int co = 0; co < Cout; ++co) acc[co] = vm_fma(a, wr[co], acc[co]);
-                            }
+            float* acc = (float*)malloc(sizeof(float) * (Cout > 16 ? Cout : 16));
+            for (int xe = 0; xe < 2; ++xe) {                               /* the two border pixels of the row */
+                const int x = xe ? W - 1 : 0;
+                if (xe && W == 1) break;
+                conv_pixel(in, wt, acc, b, y, x, H, W, Hi, Wi, Cin, Cout, up2, 0, Cout);
+                conv_store(acc, 0, Cout, bias, resid, out, b, y, x, H, W, Cout, out_mode);
+            }
+            for (int x0 = 1; x0 < W - 1; x0 += GEMM_MR) {
+                const int npx = (x0 + GEMM_MR < W - 1 ? x0 + GEMM_MR : W - 1) - x0;
+                for (int co0 = 0; co0 < Cout; co0 += 16) {
+                    if (co0 + 16 > Cout) {                                 /* ragged last channel block: pixel by pixel */
+                        for (int r = 0; r < npx; ++r) {
+                            conv_pixel(in, wt, acc, b, y, x0 + r, H, W, Hi, Wi, Cin, Cout, up2, co0, Cout);
+                            conv_store(acc, co0, Cout, bias, resid, out, b, y, x0 + r, H, W, Cout, out_mode);
                         }
+                        continue;
                     }
-                }
-                for (int co = 0; co < Cout; ++co) {
-                    float v = acc[co] + bias[co];
-                    if (resid) v = v + resid[(((int64_t)b * H + y) * W + x) * Cout + co];
-                    if (out_mode != 0) {
-                        v = vm_min(vm_max(v, -1.0f), 1.0f);                       /* vqvae.py:63 clamp_(-1,1) */
-                        out[(((int64_t)b * Cout + co) * H + y) * W + x] = out_mode == 1 ? (v + 1.0f) * 0.5f : v;   /* var.py:190 add_(1).mul_(0.5) */
-                    } else out[(((int64_t)b * H + y) * W + x) * Cout + co] = v;
+                    __m256 c[GEMM_MR][2];
+                    for (int r = 0; r < GEMM_MR; ++r) { c[r][0] = _mm256_setzero_ps(); c[r][1] = _mm256_setzero_ps(); }
+                    for (int c0 = 0; c0 < Cin; c0 += 32) {
+                        const int c1 = c0 + 32 < Cin ? c0 + 32 : Cin;
+                        for (int ky = 0; ky < 3; ++ky)
+                            for (int kx = 0; kx < 3; ++kx) {
+                                const float* ip[GEMM_MR];
+                                int sy, sx, ok = 1;
+                                for (int r = 0; r < GEMM_MR; ++r) {        /* (pixels past the block: a repeat of its last one, discarded) */
+                                    if (!conv_src(up2, H, W, Hi, Wi, y, x0 + (r < npx ? r : npx - 1), ky, kx, &sy, &sx)) { ok = 0; break; }   /* only the row can be outside: all six or none */
+                                    ip[r] = in + (((int64_t)b * Hi + sy) * Wi + sx) * Cin;
+                                }
+                                if (!ok) continue;
+                                const float* wp = wt + ((int64_t)(ky * 3 + kx) * Cin) * Cout + co0;
+                                for (int ci = c0; ci < c1; ++ci) {
+                                    const __m256 b0 = _mm256_loadu_ps(wp + (int64_t)ci * Cout), b1 = _mm256_loadu_ps(wp + (int64_t)ci * Cout + 8);
+                                    for (int r = 0; r < GEMM_MR; ++r) {
+                                        const __m256 av = _mm256_broadcast_ss(ip[r] + ci);
+                                        c[r][0] = _mm256_fmadd_ps(av, b0, c[r][0]);
+                                        c[r][1] = _mm256_fmadd_ps(av, b1, c[r][1]);
+                                    }
+                                }
+                            }
+                    }
+                    for (int r = 0; r < npx; ++r) {
+                        _mm256_storeu_ps(acc, c[r][0]); _mm256_storeu_ps(acc + 8, c[r][1]);
+                        conv_store(acc, co0, co0 + 16, bias, resid, out, b, y, x0 + r, H, W, Cout, out_mode);
+                    }
                 }
             }
             free(acc);
