@@ -575,9 +575,10 @@ def test_f16_mode_properties_d16_full():
     assert torch.equal(eng.sample(B, labels, None, 1.5, 900, 0.96, noises=noise), base32)
 
 
-@pytest.mark.parametrize('depth,saln,pns', [(30, False, (1, 2, 3, 4, 5, 6, 8, 10, 13, 16)), (36, True, (1, 2, 3, 4, 6, 9, 13, 18, 24, 32))],
-                         ids=['d30_256px_f16', 'd36_512px_f16'])
-def test_full_size_wide_models_properties_f16(depth, saln, pns):
+@pytest.mark.parametrize('depth,saln,pns,flav', [(30, False, (1, 2, 3, 4, 5, 6, 8, 10, 13, 16), 'f16'), (36, True, (1, 2, 3, 4, 6, 9, 13, 18, 24, 32), 'f16'),
+                                                 (36, True, (1, 2, 3, 4, 6, 9, 13, 18, 24, 32), 'bf16')],
+                         ids=['d30_256px_f16', 'd36_512px_f16', 'd36_512px_bf16'])
+def test_full_size_wide_models_properties_f16(depth, saln, pns, flav):
     """BASELINE.json configs[3] / configs[4] at FULL size in the precision configs[4] names (fp16): VAR-d30 256x256 (L = 680) and VAR-d36 512x512
     (patch_nums up to 32, L = 2240, KV cache reused across scales, 36 heads), B=2 on one GPU, through the size-independent checks (the
     f32 counterpart is tests/test_e2e_gpu.py::test_full_size_wide_models_properties): determinism, batch-slice invariance of the tokens,
@@ -594,7 +595,7 @@ def test_full_size_wide_models_properties_f16(depth, saln, pns):
     labels = torch.tensor([207, 980], device='cuda')
     eng.sample(B, labels, None, 1.5, 900, 0.96, noises=noise, trace=True, decode=False)
     idx32 = torch.cat(eng.last_trace['idx'], dim=1)
-    var.set_hip_precision('f16')
+    var.set_hip_precision(flav)
     try:
         img = eng.sample(B, labels, None, 1.5, 900, 0.96, noises=noise, trace=True).clone()
         tr = eng.last_trace
@@ -608,7 +609,7 @@ def test_full_size_wide_models_properties_f16(depth, saln, pns):
         assert torch.equal(img, img2) and torch.equal(idx, torch.cat(eng.last_trace['idx'], dim=1))
         sub = eng.sample(1, labels[1:], None, 1.5, 900, 0.96, noises=[n.view(B, -1, V)[1:].reshape(-1, V) for n in noise], trace=True)
         assert torch.equal(torch.cat(eng.last_trace['idx'], dim=1), idx[1:]), 'tokens must not depend on the batch neighbours'
-        assert float((sub - img[1:]).abs().max()) <= 5e-3         # (conv16 kernel choice and GroupNorm partial order follow the batch: test_f16_mode_properties_d16_full)
+        assert float((sub - img[1:]).abs().max()) <= (5e-3 if flav == 'f16' else 4e-2)         # (conv16 kernel choice and GroupNorm partial order follow the batch: test_f16_mode_properties_d16_full)
         ms, cur = [], 0
         for pn in pns:
             ms.append(idx[:, cur:cur + pn * pn].contiguous()); cur += pn * pn
@@ -620,15 +621,16 @@ def test_full_size_wide_models_properties_f16(depth, saln, pns):
             hs = [vae.quantize.embedding(i).transpose(1, 2).reshape(B, vae.Cvae, pn, pn) for i, pn in zip(ms, pns)]
             assert torch.equal(vae.quantize.embed_to_fhat(hs, all_to_max_scale=True, last_one=True), f_hat)
             im32 = vae.idxBl_to_img(ms, same_shape=True, last_one=True).add_(1).mul_(0.5)           # the VQVAE's own entry points stay fp32 ...
-            vae._decoder_engine().set_precision('f16')                                                # ... unless its owner asks for fp16
+            vae._decoder_engine().set_precision(flav)                                                 # ... unless its owner asks for the 16-bit decoder
             try:
                 im16 = vae.idxBl_to_img(ms, same_shape=True, last_one=True).add_(1).mul_(0.5)
             finally:
                 vae._decoder_engine().set_precision('f32')
         assert torch.equal(im16, img)
         d = (im32 - img).abs()
-        print(f'd{depth} f16: decoder f16 vs f32 on the same tokens max |d| {float(d.max()):.3e} mean {float(d.mean()):.3e}; '
+        print(f'd{depth} {flav}: decoder {flav} vs f32 on the same tokens max |d| {float(d.max()):.3e} mean {float(d.mean()):.3e}; '
               f'free-running token agreement with the f32 mode {float((idx == idx32).float().mean()):.3f}')
-        assert float(d.max()) <= 3e-2 and float(d.mean()) <= 2e-3          # [0,1] range: half of test_decoder16_vs_fp32_decoder's [-1,1] bounds
+        k = 1.0 if flav == 'f16' else 3.0                                # (bf16: 3 bits fewer per rounding, measured 2.8e-2 / 2.6e-3; tests/test_bf16_gpu.py)
+        assert float(d.max()) <= 3e-2 * k and float(d.mean()) <= 2e-3 * k          # [0,1] range: half of test_decoder16_vs_fp32_decoder's [-1,1] bounds
     finally:
         var.set_hip_precision('f32')
