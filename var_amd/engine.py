@@ -582,12 +582,14 @@ class EncoderEngine(DecoderEngine):
 
 
 class SamplingEngine:
+    MAX_WORKSPACES = 4          # per-stream buffer sets kept alive (workspace())
     """The AR loop of VAR.autoregressive_infer_cfg on HIP kernels.  One engine per VAR module; not re-entrant."""
 
     def __init__(self, var):
         self.var = var
         self._sig = None
         self._ws: Dict[tuple, dict] = {}            # (batch size, HIP stream) -> buffers of a call
+
         self.precision = 'f32'              # 'f16': the 16-bit throughput mode of the transformer (include/var_hip.h "f16"), explicitly selected
         self.dec = var.vae_proxy[0]._decoder_engine()       # the VQVAE's own engine: one packed copy of the decoder weights, one place to invalidate
         self.last_trace: Optional[dict] = None
@@ -695,6 +697,8 @@ class SamplingEngine:
                   vc=[torch.zeros(2 * B, H, L, 64, dtype=act, device=dev) for _ in range(var.depth)],
                   f_hat=e(B, P, P, Cv), up=e(B, P, P, Cv), pooled=e(B * lmax, Cv))
         self._ws = {k: v for k, v in self._ws.items() if k[1] != sid}          # one batch size resident at a time (per stream)
+        while len(self._ws) >= self.MAX_WORKSPACES:                             # ... and a bounded number of streams (oldest first: a d16 / B=64 set is 6-11 GB;
+            self._ws.pop(next(iter(self._ws)))                                  # its memory returns to the stream it was allocated on, so work still queued there is safe)
         self._ws[(B, sid)] = ws
         return ws
 
