@@ -192,6 +192,28 @@ def run_sampler(iters):
     print(f'sampler total (parallel cut) {tot_ms:.3f} ms per step, {tot_b / tot_ms / 1e6:.1f} GB/s of 8000', flush=True)
 
 
+def run_tail(iters):
+    """the decoder's tail (norm_out -> swish -> conv_out -> clamp) at the d16 / B=64 shape: the one-pass kernels against the two launches they replace"""
+    B, H, W, Cin, Cout, omode = 64, 256, 256, 160, 3, 1
+    gamma, beta = torch.randn(Cin, device='cuda') * 0.2 + 1.0, torch.randn(Cin, device='cuda') * 0.2
+    bias = torch.randn(Cout, device='cuda') * 0.1
+    stats = torch.empty(B, 32, 2, dtype=torch.float32, device='cuda')
+    out = torch.empty(B, Cout, H, W, device='cuda')
+    for flav, dt in (('f32', torch.float32), ('f16', torch.float16), ('bf16', torch.bfloat16)):
+        x = (torch.randn(B, H, W, Cin, device='cuda') * 1.3 + 0.2).to(dt)
+        w = (torch.randn(Cout, 3, 3, Cin, device='cuda') * 0.05).to(dt)
+        scratch = torch.empty(hip.gn_scratch_elems(B, H * W, Cin, 32), dtype=torch.float64, device='cuda')
+        hip.call('gn_stats_' + flav, x, stats, scratch, B, H * W, Cin, 32, 1e-6)
+        xn = torch.empty_like(x)
+        fused = timeit(lambda: hip.call('gn_silu_conv_out_' + flav, x, stats, gamma, beta, w, bias, out, B, H, W, Cin, Cout, 32, omode), iters)
+        apply = timeit(lambda: hip.call('gn_apply_' + flav, x, stats, gamma, beta, xn, B, H * W, Cin, 32, 1), iters)
+        if flav == 'f32': conv = timeit(lambda: hip.call('conv3x3_nhwc_f32', xn, w, bias, None, out, B, H, W, Cin, Cout, 0, omode), iters)
+        else: conv = timeit(lambda: hip.call('conv3x3_nhwc_' + flav, xn, w, bias, None, out, None, B, H, W, Cin, Cout, omode), iters)
+        gb = x.numel() * x.element_size() / 1e9
+        print(f'tail {flav:4s}: one pass {fused * 1e3:8.1f} us ({gb / (fused * 1e-3):7.1f} GB/s of input)   GroupNorm apply {apply * 1e3:8.1f} us + conv_out {conv * 1e3:8.1f} us', flush=True)
+        del x, xn, w, scratch
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('what', nargs='?', default='all')
@@ -207,3 +229,4 @@ if __name__ == '__main__':
     if a.what in ('gemm16', 'all16'): run_gemm16(a.iters)
     if a.what in ('attn16', 'all16'): run_attn16(a.iters)
     if a.what in ('sampler', 'all'): run_sampler(a.iters)
+    if a.what == 'tail': run_tail(a.iters)
