@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(256) k_cfg_sample(const float* __restrict__ lo
     extern __shared__ __attribute__((aligned(16))) unsigned char sm_raw[];
     float* xs = reinterpret_cast<float*>(sm_raw);                                   // [V] working logits
     unsigned long long* srt = reinterpret_cast<unsigned long long*>(sm_raw + sizeof(float) * V);   // [cap] (key<<32 | idx), cap = pow2 >= top_k (or V)
-    __shared__ int s_hist[2][256];
+    __shared__ __attribute__((aligned(8))) int s_hist[2][256];      // top-k: two count tables; top-p (3a): one table of 256 doubles (the probability mass per byte value)
     __shared__ int s_ci[8];
     __shared__ double s_cd[4];
     __shared__ float red[4];
@@ -48,6 +48,7 @@ __global__ void __launch_bounds__(256) k_cfg_sample(const float* __restrict__ lo
     __shared__ int s_sel[2];
     __shared__ int s_flag;
     __shared__ float s_bv[4]; __shared__ int s_bi[4]; __shared__ int s_bn[4];
+    __shared__ double s_c0; __shared__ int s_pick; __shared__ int s_fast; __shared__ int s_ntie; __shared__ unsigned s_tie[64];     // top-p by selection (3a)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t row = blockIdx.x;
@@ -121,6 +122,94 @@ __global__ void __launch_bounds__(256) k_cfg_sample(const float* __restrict__ lo
         }
         __syncthreads();
         const int cnt = (int)s_cnt;
+        // (3a) The cut WITHOUT sorting.  The removed set is a prefix of the ascending (key, index) order: every entry whose running sum
+        // c (fp64, ascending) satisfies (float)c <= thr, i.e. c below `mid`, the midpoint of thr and the next float.  That prefix is found
+        // by selection, the way top-k found its threshold: four passes over the key bytes, each summing the probability mass per byte value
+        // and walking the 256 sums upwards to the value where the running mass crosses mid.  Result: the key K* of the entry at which the
+        // running sum crosses, and C0 = the mass of everything below K*.  Entries below K* go; the (normally one) entries equal to K* are
+        // taken in index order.  The sums are formed in another order than the sequential walk's, so they differ from its running sums by
+        // at most n * 2^-53 (relative): the decision is the walk's whenever the two running sums next to the cut — the last removed
+        // entry's and the first kept one's — are farther than 1e-9 (relative) from mid, which is checked; otherwise, and for tie crowds,
+        // the sort + walk below decides as before (varhip_sampler_force_walk(1) forces it: the tests compare both against the oracle).
+        bool cut_done = false;
+        if (!split && thr > 1e-30f && cnt >= 2 && !force_walk) {
+            const double mid = 0.5 * ((double)thr + (double)__uint_as_float(__float_as_uint(thr) + 1u));
+            double* const s_hs = reinterpret_cast<double*>(&s_hist[0][0]);
+            // the probability of an entry from its key (vm_float_key is invertible: -0 was folded into +0, which has the same exponential)
+            auto prob_of = [&](unsigned key) { const unsigned u = (key & 0x80000000u) ? (key & 0x7FFFFFFFu) : ~key; return vm_exp(__uint_as_float(u) - m) / S; };
+            unsigned prefix = 0u, mask = 0u;
+            double C0 = 0.0;
+            bool ok = true;
+#pragma unroll 1
+            for (int pass = 0; pass < 4 && ok; ++pass) {
+                const int shift = 24 - 8 * pass;
+                s_hs[tid] = 0.0;
+                if (tid == 0) s_pick = -1;
+                __syncthreads();
+                for (int e0 = 0; e0 < cnt; e0 += 256) {                   // (wave-uniform trip count)
+                    const int e = e0 + tid;
+                    const unsigned key = e < cnt ? (unsigned)(srt[e] >> 32) : 0u;
+                    const bool cand = e < cnt && (key & mask) == prefix;
+                    const int bkt = (int)((key >> shift) & 255u);
+                    double pv = cand ? (double)prob_of(key) : 0.0;
+                    // the survivors' keys cluster (one or two values of the leading byte): when a wave's candidates all fall into one value,
+                    // the wave adds them up itself and issues ONE atomic instead of 64 on the same address
+                    const unsigned long long bc = __ballot(cand);
+                    if (bc) {
+                        const int b0 = __shfl(bkt, __ffsll((long long)bc) - 1, 64);
+                        if (__ballot(cand && bkt != b0) == 0ull) {
+#pragma unroll
+                            for (int off = 32; off >= 1; off >>= 1) pv += __shfl_xor(pv, off, 64);
+                            if (lane == 0) atomicAdd(&s_hs[b0], pv);
+                        } else if (cand) atomicAdd(&s_hs[bkt], pv);
+                    }
+                }
+                __syncthreads();
+                const double mine = s_hs[tid];
+                const double incl = vs_scan256_d(mine, s_cd);            // thread t owns byte value t: mass of the candidates with a byte <= t
+                if (mine > 0.0 && C0 + incl > mid && !(C0 + (incl - mine) > mid)) { s_pick = tid; s_c0 = C0 + (incl - mine); }
+                __syncthreads();
+                if (s_pick < 0) ok = false;                              // (the whole mass stays below mid: degenerate, the walk decides)
+                else { prefix |= (unsigned)s_pick << shift; mask |= 255u << shift; C0 = s_c0; }
+                __syncthreads();
+            }
+            if (tid == 0) { s_ntie = 0; s_fast = ok ? 1 : 0; }
+            __syncthreads();
+            if (ok) {
+                // entries equal to K* (ties share one probability): listed, ranked by index, each one's running sum formed by repeated addition
+                for (int e = tid; e < cnt; e += 256)
+                    if ((unsigned)(srt[e] >> 32) == prefix) { const int q = atomicAdd(&s_ntie, 1); if (q < 64) s_tie[q] = (unsigned)srt[e]; }
+                __syncthreads();
+                const int ntie = s_ntie;
+                if (ntie > 64 || fabs(C0 - mid) <= 1e-9 * mid) { if (tid == 0) s_fast = 0; }
+                __syncthreads();
+                unsigned rm = 0u;                                        // bit k: this thread's k-th entry is removed
+                if (s_fast) {
+                    const double pT = (double)prob_of(prefix);
+                    int k = 0;
+                    for (int e = tid; e < cnt; e += 256, ++k) {
+                        const unsigned key = (unsigned)(srt[e] >> 32), idx = (unsigned)srt[e];
+                        if (key < prefix) rm |= 1u << k;
+                        else if (key == prefix) {
+                            int rank = 0;
+                            for (int q = 0; q < ntie; ++q) rank += (s_tie[q] < idx) ? 1 : 0;
+                            double c = C0;
+                            for (int q = 0; q <= rank; ++q) c += pT;
+                            if (fabs(c - mid) <= 1e-9 * mid) atomicAnd(&s_fast, 0);
+                            else if (c < mid) rm |= 1u << k;
+                        }
+                    }
+                }
+                __syncthreads();
+                if (s_fast) {
+                    int k = 0;
+                    for (int e = tid; e < cnt; e += 256, ++k) if ((rm >> k) & 1u) xs[(unsigned)srt[e]] = -INFINITY;
+                    cut_done = true;
+                }
+            }
+            __syncthreads();
+        }
+        if (!cut_done) {
         int n2 = 2; while (n2 < cnt) n2 <<= 1;
         for (int i = cnt + tid; i < n2; i += 256) srt[i] = ~0ull;       // pad to a power of two with +max keys
         __syncthreads();
@@ -217,6 +306,7 @@ __global__ void __launch_bounds__(256) k_cfg_sample(const float* __restrict__ lo
                 }
             }
         }
+        }   // !cut_done
         __syncthreads();
     }
 
