@@ -34,6 +34,9 @@ __device__ __forceinline__ double vs_scan256_d(double v, double* sw) {
     return v + add;
 }
 
+// NV = V / 256 when the caller's V is the common 4096 (the exponentials of a thread's NV elements then stay in registers between the
+// phases: one evaluation instead of three), 0 = any V (evaluated where needed)
+template <int NV>
 __global__ void __launch_bounds__(256) k_cfg_sample(const float* __restrict__ logits, const float* __restrict__ noise, int64_t* __restrict__ idx_out,
                                                     float* __restrict__ masked_out, int64_t rows, int V, float ca, float cb,
                                                     int top_k, int use_top_p, float thr, int cap, int force_walk) {
@@ -91,11 +94,16 @@ __global__ void __launch_bounds__(256) k_cfg_sample(const float* __restrict__ lo
     float m = -INFINITY;
     for (int i = tid; i < V; i += 256) m = fmaxf(m, xs[i]);
     m = vh_block_max256(m, red);
+    float ev[NV > 0 ? NV : 1];                                      // (NV > 0) exp(x - m) of this thread's elements
 
     // (3) top-p
     if (use_top_p) {
         float part = 0.f;
         int fin = 0;
+        if constexpr (NV > 0) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) { const float x = xs[tid + 256 * k]; ev[k] = vm_exp(x - m); part = part + ev[k]; fin += (x > -INFINITY) ? 1 : 0; }
+        } else
         for (int i = tid; i < V; i += 256) { part = part + vm_exp(xs[i] - m); fin += (xs[i] > -INFINITY) ? 1 : 0; }
         const float S = vh_block_sum256(part, red);
 #pragma unroll
@@ -312,16 +320,25 @@ __global__ void __launch_bounds__(256) k_cfg_sample(const float* __restrict__ lo
 
     // (4) softmax of what is left, divide by the Exp(1) noise, arg-max (first max; NaN wins, as torch.argmax)
     float part = 0.f;
+    if constexpr (NV > 0) {
+        // what top-p removed (and top-k before it) is -inf now: exp(-inf - m) is exactly 0; everything else kept its exponential
+#pragma unroll
+        for (int k = 0; k < NV; ++k) { const float x = xs[tid + 256 * k]; ev[k] = use_top_p ? (x == -INFINITY ? 0.0f : ev[k]) : vm_exp(x - m); part = part + ev[k]; }
+    } else
     for (int i = tid; i < V; i += 256) part = part + vm_exp(xs[i] - m);
     const float S = vh_block_sum256(part, red);
     const float* qn = noise + row * V;
     float bv = 0.f; int bi = -1; int bn = 0;
-    for (int i = tid; i < V; i += 256) {
-        const float rv = (vm_exp(xs[i] - m) / S) / qn[i];
+    auto consider = [&](float rv, int i) {
         const int isn = (rv != rv);
         if (bi < 0) { bv = rv; bi = i; bn = isn; }
         else if (!bn && (isn || rv > bv)) { bv = rv; bi = i; bn = isn; }
-    }
+    };
+    if constexpr (NV > 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) consider((ev[k] / S) / qn[tid + 256 * k], tid + 256 * k);
+    } else
+    for (int i = tid; i < V; i += 256) consider((vm_exp(xs[i] - m) / S) / qn[i], i);
     // combine across threads: NaN beats number; larger beats smaller; ties -> smaller index
     auto better = [](float av, int ai, int an, float cv, int ci, int cn) -> bool {      // is (c) better than (a)?
         if (ci < 0) return false;
@@ -356,10 +373,15 @@ extern "C" int varhip_cfg_sample_f32(const float* logits, const float* noise, in
     int cap = 2; while (cap < (top_k > 0 ? top_k : V)) cap <<= 1;       // sort buffer entries (see the kernel: ties beyond it are handled unsorted)
     const size_t lds = sizeof(float) * (size_t)V + sizeof(unsigned long long) * (size_t)cap;
     static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute((const void*)k_cfg_sample, hipFuncAttributeMaxDynamicSharedMemorySize, 12 * 8192); attr_done = true; }
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)k_cfg_sample<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 12 * 8192);
+                      (void)hipFuncSetAttribute((const void*)k_cfg_sample<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 12 * 8192); attr_done = true; }
     VhScope sc(VH_FAM_SAMPLER, (hipStream_t)stream, 0, 4.0 * rows * V * 3.0);
-    hipLaunchKernelGGL(k_cfg_sample, dim3((unsigned)rows), dim3(256), lds, (hipStream_t)stream, logits, noise, idx_out, masked_out, rows, V,
-                       (float)(1.0 + t_cfg), (float)t_cfg, top_k, top_p > 0.0 ? 1 : 0, (float)(1.0 - top_p), cap, g_sampler_force_walk);
+    if (V == 4096)
+        hipLaunchKernelGGL(k_cfg_sample<16>, dim3((unsigned)rows), dim3(256), lds, (hipStream_t)stream, logits, noise, idx_out, masked_out, rows, V,
+                           (float)(1.0 + t_cfg), (float)t_cfg, top_k, top_p > 0.0 ? 1 : 0, (float)(1.0 - top_p), cap, g_sampler_force_walk);
+    else
+        hipLaunchKernelGGL(k_cfg_sample<0>, dim3((unsigned)rows), dim3(256), lds, (hipStream_t)stream, logits, noise, idx_out, masked_out, rows, V,
+                           (float)(1.0 + t_cfg), (float)t_cfg, top_k, top_p > 0.0 ? 1 : 0, (float)(1.0 - top_p), cap, g_sampler_force_walk);
     return vh_launch_status();
 }
 
