@@ -59,7 +59,20 @@ __global__ void __launch_bounds__(256) k_cfg_sample(const float* __restrict__ lo
     const float* lu = logits + (rows + row) * V;
 
     // (1) CFG combine: (1+t)*cond - t*uncond, three roundings as in the reference's tensor expression
-    for (int i = tid; i < V; i += 256) { const float a = ca * lc[i]; const float b = cb * lu[i]; xs[i] = a - b; }
+    // (16 bytes per lane; which thread computes an element is irrelevant here — the sums below read xs in their own canonical assignment)
+    for (int i4 = tid; i4 < (V >> 2); i4 += 256) {
+        const f32x4 c4 = *(const f32x4*)(lc + 4 * i4), u4 = *(const f32x4*)(lu + 4 * i4);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float a = ca * c4[e]; const float b = cb * u4[e]; o[e] = a - b; }
+        *(f32x4*)(xs + 4 * i4) = o;
+    }
+    // the row's Exp(1) noise is needed last: requested now (NV > 0: into registers), it arrives behind everything else
+    float qv[NV > 0 ? NV : 1];
+    if constexpr (NV > 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) qv[k] = noise[row * V + tid + 256 * k];
+    }
     s_hist[0][tid] = 0;
     __syncthreads();
 
@@ -336,7 +349,7 @@ __global__ void __launch_bounds__(256) k_cfg_sample(const float* __restrict__ lo
     };
     if constexpr (NV > 0) {
 #pragma unroll
-        for (int k = 0; k < NV; ++k) consider((ev[k] / S) / qn[tid + 256 * k], tid + 256 * k);
+        for (int k = 0; k < NV; ++k) consider((ev[k] / S) / qv[k], tid + 256 * k);
     } else
     for (int i = tid; i < V; i += 256) consider((vm_exp(xs[i] - m) / S) / qn[i], i);
     // combine across threads: NaN beats number; larger beats smaller; ties -> smaller index
@@ -369,6 +382,7 @@ extern "C" int varhip_sampler_force_walk(int on) { g_sampler_force_walk = on ? 1
 extern "C" int varhip_cfg_sample_f32(const float* logits, const float* noise, int64_t* idx_out, float* masked_out,
                                      int B, int l, int V, double t_cfg, int top_k, double top_p, varhip_stream_t stream) {
     if (B <= 0 || l <= 0 || V <= 0 || (V & 255) || V > 8192 || top_k < 0 || top_k > V) return VARHIP_EINVAL;
+    if ((uintptr_t)logits & 15) return VARHIP_EINVAL;                 // (rows are read 16 bytes per lane)
     const int64_t rows = (int64_t)B * l;
     int cap = 2; while (cap < (top_k > 0 ? top_k : V)) cap <<= 1;       // sort buffer entries (see the kernel: ties beyond it are handled unsorted)
     const size_t lds = sizeof(float) * (size_t)V + sizeof(unsigned long long) * (size_t)cap;
