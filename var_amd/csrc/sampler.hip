@@ -34,6 +34,20 @@ __device__ __forceinline__ double vs_scan256_d(double v, double* sw) {
     return v + add;
 }
 
+__device__ __forceinline__ unsigned long long vs_scan256_u64(unsigned long long v, unsigned long long* sw) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned lo = __shfl_up((unsigned)v, off, 64), hi = __shfl_up((unsigned)(v >> 32), off, 64);
+        if (lane >= off) v += ((unsigned long long)hi << 32) | lo;
+    }
+    if (lane == 63) sw[wave] = v;
+    __syncthreads();
+    unsigned long long add = 0ull;
+    for (int w = 0; w < wave; ++w) add += sw[w];
+    return v + add;
+}
+
 // NV = V / 256 when the caller's V is the common 4096 (the exponentials of a thread's NV elements then stay in registers between the
 // phases: one evaluation instead of three), 0 = any V (evaluated where needed)
 template <int NV>
@@ -155,43 +169,35 @@ __global__ void __launch_bounds__(256) k_cfg_sample(const float* __restrict__ lo
         bool cut_done = false;
         if (!split && thr > 1e-30f && cnt >= 2 && !force_walk) {
             const double mid = 0.5 * ((double)thr + (double)__uint_as_float(__float_as_uint(thr) + 1u));
-            double* const s_hs = reinterpret_cast<double*>(&s_hist[0][0]);
+            // The mass per byte value is summed in 2^-62 fixed point: integer LDS atomics do not mind the contention that the survivors'
+            // clustered leading bytes put on a few addresses (fp64 atomics on one address serialise badly), the sums are exact in that grid and
+            // the same in every run; rounding a probability to the grid moves a sum by <= n * 2^-62 absolute — far inside the 1e-9 band below.
+            unsigned long long* const s_hs = reinterpret_cast<unsigned long long*>(&s_hist[0][0]);
+            unsigned long long* const s_cu = reinterpret_cast<unsigned long long*>(s_cd);
+            const double FX = 4611686018427387904.0, IFX = 1.0 / 4611686018427387904.0;       // 2^62
             // the probability of an entry from its key (vm_float_key is invertible: -0 was folded into +0, which has the same exponential)
             auto prob_of = [&](unsigned key) { const unsigned u = (key & 0x80000000u) ? (key & 0x7FFFFFFFu) : ~key; return vm_exp(__uint_as_float(u) - m) / S; };
             unsigned prefix = 0u, mask = 0u;
+            unsigned long long C0u = 0ull;
             double C0 = 0.0;
             bool ok = true;
 #pragma unroll 1
             for (int pass = 0; pass < 4 && ok; ++pass) {
                 const int shift = 24 - 8 * pass;
-                s_hs[tid] = 0.0;
+                s_hs[tid] = 0ull;
                 if (tid == 0) s_pick = -1;
                 __syncthreads();
-                for (int e0 = 0; e0 < cnt; e0 += 256) {                   // (wave-uniform trip count)
-                    const int e = e0 + tid;
-                    const unsigned key = e < cnt ? (unsigned)(srt[e] >> 32) : 0u;
-                    const bool cand = e < cnt && (key & mask) == prefix;
-                    const int bkt = (int)((key >> shift) & 255u);
-                    double pv = cand ? (double)prob_of(key) : 0.0;
-                    // the survivors' keys cluster (one or two values of the leading byte): when a wave's candidates all fall into one value,
-                    // the wave adds them up itself and issues ONE atomic instead of 64 on the same address
-                    const unsigned long long bc = __ballot(cand);
-                    if (bc) {
-                        const int b0 = __shfl(bkt, __ffsll((long long)bc) - 1, 64);
-                        if (__ballot(cand && bkt != b0) == 0ull) {
-#pragma unroll
-                            for (int off = 32; off >= 1; off >>= 1) pv += __shfl_xor(pv, off, 64);
-                            if (lane == 0) atomicAdd(&s_hs[b0], pv);
-                        } else if (cand) atomicAdd(&s_hs[bkt], pv);
-                    }
+                for (int e = tid; e < cnt; e += 256) {
+                    const unsigned key = (unsigned)(srt[e] >> 32);
+                    if ((key & mask) == prefix) atomicAdd(&s_hs[(key >> shift) & 255u], (unsigned long long)((double)prob_of(key) * FX));
                 }
                 __syncthreads();
-                const double mine = s_hs[tid];
-                const double incl = vs_scan256_d(mine, s_cd);            // thread t owns byte value t: mass of the candidates with a byte <= t
-                if (mine > 0.0 && C0 + incl > mid && !(C0 + (incl - mine) > mid)) { s_pick = tid; s_c0 = C0 + (incl - mine); }
+                const unsigned long long mine = s_hs[tid];
+                const unsigned long long incl = vs_scan256_u64(mine, s_cu);   // thread t owns byte value t: mass of the candidates with a byte <= t
+                if (mine > 0ull && (double)(C0u + incl) * IFX > mid && !((double)(C0u + (incl - mine)) * IFX > mid)) { s_pick = tid; s_c0 = (double)(C0u + (incl - mine)) * IFX; s_hs[0] = C0u + (incl - mine); }
                 __syncthreads();
                 if (s_pick < 0) ok = false;                              // (the whole mass stays below mid: degenerate, the walk decides)
-                else { prefix |= (unsigned)s_pick << shift; mask |= 255u << shift; C0 = s_c0; }
+                else { prefix |= (unsigned)s_pick << shift; mask |= 255u << shift; C0 = s_c0; C0u = s_hs[0]; }
                 __syncthreads();
             }
             if (tid == 0) { s_ntie = 0; s_fast = ok ? 1 : 0; }
