@@ -88,3 +88,50 @@ def test_bench_under_a_one_rank_torchrun_launch():
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1 and json.loads(lines[0])['n_gpus'] == 1
+
+
+_SHARD_CHILD = r'''
+import contextlib, io, os, sys, torch
+import torch.distributed as tdist
+sys.path.insert(0, os.environ["VAR_AMD_ROOT"])
+from var_amd import dist, detinit
+from var_amd.multi import sample_sharded
+from models import build_vae_var
+dist.initialize(backend="gloo")                          # two ranks on ONE card: RCCL refuses a duplicate GPU, the shards meet on the host
+rank, world = dist.get_rank(), dist.get_world_size()
+assert world == 2
+pns, depth, B = (1, 2, 3, 4, 5, 6, 8, 10, 13, 16), 16, 4
+with contextlib.redirect_stdout(io.StringIO()):
+    vae, var = build_vae_var(device="cuda", patch_nums=pns, depth=depth, ch=160)
+detinit.fill_module_device_(var, depth, 0, "var."); detinit.fill_module_device_(vae, depth, 0, "vae.")
+var.eval(); vae.eval(); var.rng = torch.Generator(device="cuda")
+labels = torch.tensor([3, 980, 207, 88], device="cuda")
+for prec in ("f32", "f16"):
+    var.set_hip_precision(prec)
+    mine = sample_sharded(var, B, labels, g_seed=7, cfg=1.5, top_k=900, top_p=0.96, rng_mode="exact", gather=False)      # this rank's two images
+    parts = [torch.empty(B // 2, 3, 256, 256) for _ in range(world)]
+    tdist.all_gather(parts, mine.cpu())
+    if rank == 0:
+        with torch.inference_mode():
+            whole = var.autoregressive_infer_cfg(B, labels, g_seed=7, cfg=1.5, top_k=900, top_p=0.96).cpu()              # the 1-GPU stream
+        got = torch.cat(parts, dim=0)
+        if prec == "f32": assert torch.equal(got, whole), float((got - whole).abs().max())
+        else: assert float((got - whole).abs().max()) <= 5e-3          # (16-bit decoder: GroupNorm partial order follows the batch, tests/test_f16_gpu.py)
+dist.barrier(); dist.finalize()
+if rank == 0: print("shard-ok")
+'''
+
+
+def test_two_ranks_on_one_card_reproduce_the_one_gpu_stream():
+    """BASELINE.json configs[2]'s partition on hardware as far as one card allows: two processes (ranks 0 and 1 of a gloo group) share the GPU,
+    each samples its half of the batch with the 'exact' RNG mode (every rank draws the whole Exp(1) fill and keeps its rows), the shards are
+    gathered on the host: rank order == batch order, and the images are the single-process call's — bit for bit in f32"""
+    port = str(util.free_port())
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK='0', WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=port,
+                   VAR_AMD_ROOT=util.ROOT, HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, '-c', _SHARD_CHILD], cwd=util.ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), '\n'.join(o[1][-1500:] for o in outs)
+    assert 'shard-ok' in outs[0][0]
