@@ -23,7 +23,7 @@ def _hip():
     return hip
 
 
-@pytest.mark.parametrize('tile', [0, 1, 2])
+@pytest.mark.parametrize('tile', [0, 1, 2, 3])
 @pytest.mark.parametrize('M,N,K,mode', [(128, 1024, 1024, 'none16'), (1152, 4096, 1024, 'gelu16'), (200, 1024, 4096, 'resid32'), (513, 520, 128, 'resid16in'),
                                         (1000, 3072, 192, 'none32'), (300, 2304, 9216, 'resid32'), (300, 5760, 1920, 'none16'), (4352, 4096, 128, 'gelu16')])
 def test_gemm_bf16_every_tile_against_float64(tile, M, N, K, mode):

@@ -55,7 +55,7 @@ def test_gemm16_against_float64(M, N, K, mode):
     assert not bool(bad.any()), f'{mode} {M}x{N}x{K}: {int(bad.sum())} outside tolerance, max err {float((got - ref).abs().max()):.3e}'
 
 
-@pytest.mark.parametrize('tile', [0, 1, 2])
+@pytest.mark.parametrize('tile', [0, 1, 2, 3])
 @pytest.mark.parametrize('M,N,K,mode', [(700, 1024, 256, 'none16'), (513, 520, 128, 'resid32'), (256, 256, 64, 'gelu16'), (1000, 3072, 192, 'none32')])
 def test_gemm16_every_tile_on_ragged_shapes(tile, M, N, K, mode):
     """the three tile instantiations (128x128, 64x64, 256x256 with 8 waves) forced onto shapes with partial tiles in both dimensions:
@@ -82,7 +82,7 @@ def test_gemm16_every_tile_on_ragged_shapes(tile, M, N, K, mode):
     assert bool(((got.double() - ref).abs() <= tol).all())
 
 
-@pytest.mark.parametrize('tile', [0, 1, 2])
+@pytest.mark.parametrize('tile', [0, 1, 2, 3])
 @pytest.mark.parametrize('N,K,mode', [(5760, 1920, 'none16'), (1920, 1920, 'resid32'), (7680, 1920, 'gelu16'), (1920, 7680, 'resid32'),
                                       (6912, 2304, 'none16'), (2304, 2304, 'resid32'), (9216, 2304, 'gelu16'), (2304, 9216, 'resid32'), (4096, 2304, 'none32')])
 def test_gemm16_at_d30_d36_widths_every_tile(tile, N, K, mode):
@@ -208,6 +208,13 @@ def test_gemm_qkv16_against_float64(B2, l, H, pos0, l2):
         hip.call('gemm_qkv_f16', A.cuda(), K, W.cuda(), K, bias.cuda(), M, C, K, smul.cuda(), 0.125, l2, q2, kc2, vc2, B2, l, H, pos0, Lmax)
     finally:
         hip.lib().so.varhip_gemm16_force_tile(-1)
+    q3 = torch.empty_like(q); kc3 = torch.zeros_like(kc); vc3 = torch.zeros_like(vc)       # ... and the 192x256 tile
+    hip.lib().so.varhip_gemm16_force_tile(3)
+    try:
+        hip.call('gemm_qkv_f16', A.cuda(), K, W.cuda(), K, bias.cuda(), M, C, K, smul.cuda(), 0.125, l2, q3, kc3, vc3, B2, l, H, pos0, Lmax)
+    finally:
+        hip.lib().so.varhip_gemm16_force_tile(-1)
+    assert torch.equal(vc, vc3) and torch.equal(q, q3) and torch.equal(kc, kc3)
     assert torch.equal(vc, vc2) and torch.equal(q, q2) and torch.equal(kc, kc2)      # every tile takes the head's sum of squares in the same order: identical bits
     ref = (A.double() @ W.double().T + bias.double()).view(B2, l, 3, H, 64)
     rq, rk, rv = ref[:, :, 0], ref[:, :, 1], ref[:, :, 2]

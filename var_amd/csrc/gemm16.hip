@@ -634,7 +634,15 @@ static int pick_tile16(int M, int N, int batch, bool resid32 = false) {
     const int64_t nb128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128) * batch;
     // (with the fp32 residual epilogue — attn.proj, ffn.fc2 — the large tile wins earlier: measured at M = 12800, N = 1024, 200 tiles on 256 CUs)
     if (nb256 >= (resid32 ? 192 : 256) && (double)nb256 / (double)(((nb256 + 255) / 256) * 256) >= (resid32 ? 0.75 : 0.8)) return 2;
-    return nb128 >= 512 ? 0 : 1;
+    if (nb128 < 512) return 1;
+    // 192x256 tiles (k_gemm16<6,4,2,4>) where their rounds cost less than the 128x128 kernel's: in units of one round of 256x256 tiles a round
+    // of 192x256 tiles costs 0.86 (0.75 of the work at 87 % of the rate) and a round of 512 128x128 tiles 0.62 (half the work at 81 %) —
+    // fitted on M = 21632, N = 1024 (l = 169: 452 tiles = 2 rounds = 1.72 against 3 x 0.62 = 1.86; measured 235 vs 251 us at K = 4096) and
+    // checked against l = 36 .. 100, where the 128x128 or the 256x256 tile stays ahead
+    const int64_t nb192 = (int64_t)((M + 191) / 192) * ((N + 255) / 256) * batch;
+    const double t192 = (double)((nb192 + 255) / 256) * 0.8625, t128 = (double)((nb128 + 511) / 512) * 0.62, t256 = (double)((nb256 + 255) / 256);
+    if (batch == 1 && nb192 >= 256 && t192 < t128 * 0.95 && t192 < t256) return 3;
+    return 0;
 }
 
 // A launch of the 256x256 kernel takes ceil(tiles / 256) rounds of (K loop + epilogue) whatever the last round's occupancy (one workgroup
@@ -672,9 +680,8 @@ static int run_gemm16(Gemm16P& p, int batch, hipStream_t stream, bool qkv, bool 
     else {
         const int pick = pick_tile16(M, p.N, batch, resid32);
         seg[0] = {0, M, pick};
-        if (pick == 2 && persist_ok && vh_g_force_tile16 < 0 && batch == 1 && (M % 256) != 0 && M > 256) {
-            seg[0] = {0, M - M % 256, 2}; seg[1] = {M - M % 256, M % 256, small_pick(M % 256)}; nseg = 2;
-        }
+        // (M % 256 != 0 with the 256x256 tile: the one-tile kernel takes the partial last row of tiles itself — the persistent kernel plus a
+        // small-tile launch for the M % 256 rows measured 140.0 against 133.8 us at M = 21632, N = 3072; `persistent` below is false then)
     }
     const char* A0 = (const char*)p.A; char* O0 = (char*)p.out; const char* R0 = (const char*)p.resid;
     int rc = 0;
@@ -690,7 +697,8 @@ static int run_gemm16(Gemm16P& p, int batch, hipStream_t stream, bool qkv, bool 
         // family "gemm16" = k_gemm16p alone (one symbol: its event average is comparable with a rocprofv3 trace); everything else "gemm16_small"
         VhScope scope(persistent ? VH_FAM_GEMM16 : VH_FAM_GEMM16_SMALL, stream, 2.0 * rows * p.N * (double)p.K * batch,
                       batch * (rows * bytes_per_row + (i ? 0.0 : bytes_fixed)));
-        if (pick == 2) rc = persistent ? launch16p(p, batch, stream) : launch16<8, 4, 2, 4>(p, batch, stream);
+        if (pick == 3) rc = launch16<6, 4, 2, 4>(p, batch, stream);
+        else if (pick == 2) rc = persistent ? launch16p(p, batch, stream) : launch16<8, 4, 2, 4>(p, batch, stream);
         else rc = small_launch(p, pick, batch, stream);
     }
     p.M = M; p.m_base = 0; p.A = (const vh_e16*)A0; p.out = O0; p.resid = R0;

@@ -53,8 +53,8 @@ int vh_g_conv16_force_wm = 0;
 
 extern "C" {
 
-// testing / experiments: force the tile of the next 16-bit GEMM calls (0: 128x128, 1: 64x64 and smaller (64x128 for q/k/v), 2: 256x256, -1: automatic)
-int varhip_gemm16_force_tile(int tile) { vh_g_force_tile16 = (tile >= 0 && tile <= 2) ? tile : -1; return 0; }
+// testing / experiments: force the tile of the next 16-bit GEMM calls (0: 128x128, 1: 64x64 and smaller (64x128 for q/k/v), 2: 256x256, 3: 192x256, -1: automatic)
+int varhip_gemm16_force_tile(int tile) { vh_g_force_tile16 = (tile >= 0 && tile <= 3) ? tile : -1; return 0; }
 // 0 = whole 256x256 tiles on k_gemm16<8,4,2,4> (one workgroup per tile), 1 (default) = on the persistent k_gemm16p
 int varhip_gemm16_persistent(int on) { vh_g_gemm16_persist = on ? 1 : 0; return 0; }
 // 0: by size; 2 / 4 / 8: force the 128-pixel / 256-pixel / halo-patch conv kernel (tests, tools/bench_kernels.py)
