@@ -627,22 +627,23 @@ static int launch16(Gemm16P& p, int batch, hipStream_t stream) {
 
 
 static int pick_tile16(int M, int N, int batch, bool resid32 = false) {
-    // 256x256 (8 waves, one workgroup per CU) when it gives every CU at least one tile and rounds of 256 lose little; 128x128 when that fills
-    // the chip at least twice over; else 64x64 (K cannot be split without a reduction pass; the small scales are launch-latency bound anyway)
+    // Which tile: a cost estimate in units of ONE ROUND of 256x256 tiles (one workgroup per CU).  A round of 192x256 tiles (one per CU) costs
+    // 0.86 (0.75 of the work at 87 % of the rate), a round of 512 128x128 tiles (two workgroups per CU) 0.62 (half the work at 81 %); a launch
+    // costs its rounds, full or not.  Fitted on the d16 / B = 64 shapes (tools/bench_kernels.py gemm16 with GEMM16_TILES=-1,0,1,2,3): e.g.
+    // M = 21632, N = 1024: 340 / 452 / 1352 tiles = 2.0 / 1.72 / 1.86 -> 192x256 (measured 261 / 235 / 251 us at K = 4096);
+    // M = 4608, N = 3072: 216 / 864 tiles = 1.0 / 1.24 -> 256x256 (35 / 39 us); M = 8192, N = 1024: 128 / 512 = 1.0 / 0.62 -> 128x128 (43 / 30 us).
+    // Below 256 tiles of 128x128 the 64-row kernels take over (K cannot be split without a reduction pass; those launches are latency-bound).
+    // (resid32 — attn.proj, ffn.fc2: the fp32 residual epilogue favours the large tile slightly: measured at M = 12800, N = 1024.)
     if (vh_g_force_tile16 >= 0) return vh_g_force_tile16;
     const int64_t nb256 = (int64_t)((M + 255) / 256) * ((N + 255) / 256) * batch;
-    const int64_t nb128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128) * batch;
-    // (with the fp32 residual epilogue — attn.proj, ffn.fc2 — the large tile wins earlier: measured at M = 12800, N = 1024, 200 tiles on 256 CUs)
-    if (nb256 >= (resid32 ? 192 : 256) && (double)nb256 / (double)(((nb256 + 255) / 256) * 256) >= (resid32 ? 0.75 : 0.8)) return 2;
-    if (nb128 < 512) return 1;
-    // 192x256 tiles (k_gemm16<6,4,2,4>) where their rounds cost less than the 128x128 kernel's: in units of one round of 256x256 tiles a round
-    // of 192x256 tiles costs 0.86 (0.75 of the work at 87 % of the rate) and a round of 512 128x128 tiles 0.62 (half the work at 81 %) —
-    // fitted on M = 21632, N = 1024 (l = 169: 452 tiles = 2 rounds = 1.72 against 3 x 0.62 = 1.86; measured 235 vs 251 us at K = 4096) and
-    // checked against l = 36 .. 100, where the 128x128 or the 256x256 tile stays ahead
     const int64_t nb192 = (int64_t)((M + 191) / 192) * ((N + 255) / 256) * batch;
-    const double t192 = (double)((nb192 + 255) / 256) * 0.8625, t128 = (double)((nb128 + 511) / 512) * 0.62, t256 = (double)((nb256 + 255) / 256);
-    if (batch == 1 && nb192 >= 256 && t192 < t128 * 0.95 && t192 < t256) return 3;
-    return 0;
+    const int64_t nb128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128) * batch;
+    if (nb128 < 256) return 1;
+    const double t256 = (double)((nb256 + 255) / 256) * (resid32 ? 0.95 : 1.0);
+    const double t192 = (batch == 1 && nb192 >= 256) ? (double)((nb192 + 255) / 256) * 0.8625 : 1e30;
+    const double t128 = (double)((nb128 + 511) / 512) * 0.62;
+    if (t256 <= t128 && t256 <= t192) return 2;
+    return t192 < t128 * 0.95 ? 3 : 0;
 }
 
 // A launch of the 256x256 kernel takes ceil(tiles / 256) rounds of (K loop + epilogue) whatever the last round's occupancy (one workgroup
