@@ -699,3 +699,29 @@ def test_decoder_f32_fused_tail_equals_unfused():
         try: b = vae.fhat_to_img(f_hat).clone()
         finally: eng.unfused_tail = False
     assert torch.equal(a, b) and torch.isfinite(a).all() and float(a.abs().max()) <= 1.0
+
+
+def test_cfg_sample_randomised_stress_exact(sampler_mode):
+    """120 random sampler configurations against the oracle, bit for bit: V in {512, 4096, 8192}, top_k from 0 to V, top_p from 1e-7 to 1 - 1e-7 and
+    0, CFG scales, logit spreads from 0.01 (near-uniform rows: long removed prefixes) to 30 (one dominant token), logits quantised to a few
+    values in a third of the cases (tie groups across the top-k and the top-p cuts), rows whose whole mass sits on one token"""
+    rng = np.random.default_rng(20261005)
+    for case in range(120):
+        V = int(rng.choice([512, 4096, 4096, 4096, 8192]))
+        B, l = 1, int(rng.integers(1, 5))
+        top_k = min(int(rng.choice([0, 1, 2, 50, 900, V // 2, V])), V)
+        top_p = float(rng.choice([0.0, 1e-7, 0.01, 0.5, 0.9, 0.96, 0.999, 1.0 - 1e-7]))
+        t = float(rng.choice([0.0, 0.3, 1.5, 4.0]))
+        scale = float(rng.choice([0.01, 0.5, 2.5, 8.0, 30.0]))
+        logits = rnd(rng, 2 * B * l, V, scale=scale)
+        if case % 3 == 0:
+            q = float(rng.choice([0.25, 1.0, 4.0]))
+            logits = (np.round(logits / q) * q).astype(np.float32)
+        if case % 10 == 7:
+            logits[:, 1:] = -1e30; logits[:, 0] = 1.0                        # one token carries all the mass (the others' exponentials are exactly 0)
+        noise = rng.exponential(1.0, (B * l, V)).astype(np.float32)
+        idx = np.zeros(B * l, np.int64); masked = np.zeros((B * l, V), np.float32)
+        (gi, gm), (wi, wm) = both('cfg_sample_f32', [logits, noise, idx, masked, B, l, V, t, top_k, top_p], [2, 3])
+        tag = f'case {case}: V={V} top_k={top_k} top_p={top_p} t={t} scale={scale}'
+        check(tag + ' kept-set', np.isfinite(gm), np.isfinite(wm))
+        check(tag + ' tokens', gi, wi)
