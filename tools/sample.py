@@ -5,7 +5,7 @@ Builds VAE + VAR with build_vae_var (same kwargs as the demo), optionally loads 
 samples class-conditional images with VAR.autoregressive_infer_cfg on the MI355X HIP path and writes a PNG grid.
 
   python tools/sample.py --depth 16 --labels 980 980 437 437 22 22 562 562 --cfg 4 --top-k 900 --top-p 0.95 --seed 0 \
-         [--vae-ckpt vae_ch160v4096z32.pth --var-ckpt var_d16.pth] --out sample.png
+         [--precision f16] [--vae-ckpt vae_ch160v4096z32.pth --var-ckpt var_d16.pth] --out sample.png
 Without checkpoints (there is no network here) the deterministic random-init weights of var_amd.detinit are used."""
 import argparse
 import contextlib
@@ -40,6 +40,8 @@ def main():
     ap.add_argument('--top-p', type=float, default=0.95)
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--more-smooth', action='store_true')
+    ap.add_argument('--precision', default='f32', choices=['f32', 'f16', 'bf16'],
+                    help="f32: token ids bit-identical to the CPU oracle; f16: what the demo's torch.autocast(dtype=float16) asks for (demo_sample.py:66-68); bf16: the same with bfloat16")
     ap.add_argument('--vae-ckpt'); ap.add_argument('--var-ckpt')
     ap.add_argument('--out', default='sample.png')
     a = ap.parse_args()
@@ -60,6 +62,7 @@ def main():
     for p in list(vae.parameters()) + list(var.parameters()): p.requires_grad_(False)
     torch.manual_seed(a.seed); np.random.seed(a.seed)
     labels = torch.tensor(a.labels, device='cuda')
+    var.set_hip_precision(a.precision)
     with torch.inference_mode():
         img = var.autoregressive_infer_cfg(B=len(a.labels), label_B=labels, cfg=a.cfg, top_k=a.top_k, top_p=a.top_p, g_seed=a.seed, more_smooth=a.more_smooth)
     grid = make_grid(img)
