@@ -17,8 +17,9 @@ Extra objects in the JSON line:
                steps between barriers, `value`, `ms_per_step`, its own measured dominant kernel with `roofline` and `whole_path`.  The
                headline `value` / `dtype` stay f32.
   modes.bf16   the same for the bfloat16 flavour of that mode.
-               Both carry `two_calls_in_flight`: the same K calls issued alternately on two HIP streams (informational: a serving loop with
-               two requests in flight; every `value` / `ms_per_step` above it is one call at a time on one stream).
+               Both carry `two_calls_in_flight` at N = 1 (at N > 1 only with --in-flight): the same K calls issued alternately on two HIP streams
+               (informational: a serving loop with two requests in flight; every `value` / `ms_per_step` above it is one call at a time on one stream).
+               At N > 1 a mode that raises is reported as modes.<dtype>.error and the headline line is still printed.
   ranks        (N > 1) each rank's own wall time per step, min and max over ranks, and the HIP-event time of the RCCL all-gather.
   roofline     the dominant kernel (largest device time among the single-symbol families, measured in the last warmup step with
                every family timed), re-timed alone with HIP events on the launch stream over the timed region: algorithmic FLOPs / time.
@@ -115,7 +116,7 @@ def run_mode(var, dtype, steps, warmup, args, world, step_fn, dist, hip, torch, 
         dist.barrier()
         dt2 = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt2], dtype=torch.float64, device=img.device)
+            t = torch.tensor([dt2], dtype=torch.float64, device=dist.collective_device(img.device))
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             dt2 = float(t.item())
         res['dt_in_flight2'] = dt2
@@ -137,7 +138,7 @@ def describe_mode(m, args, world, var, pns):
     kname = DOMINANT[dtype][dominant]
     peak = FAMILY_PEAK[dominant]
     traffic, tsrc = None, None                                   # HBM-side bytes per launch from a separate rocprofv3 --pmc pass of the same config
-    for prof in () if dtype == 'bf16' else (f'r03_{dtype}_pmc_traffic.json', f'r02_{dtype}_pmc_traffic.json'):
+    for prof in (f'r04_{dtype}_pmc_traffic.json',) + (() if dtype == 'bf16' else (f'r03_{dtype}_pmc_traffic.json', f'r02_{dtype}_pmc_traffic.json')):
         try:
             pj = json.load(open(os.path.join(ROOT, 'profiles', prof)))
             pm = pj['kernels'].get(kname)
@@ -187,6 +188,10 @@ def main():
     ap.add_argument('--dtype', default='f32', choices=['f32', 'f16', 'bf16'], help='the mode of the headline value (default f32: the parity contract)')
     ap.add_argument('--no-modes', action='store_true', help='skip the extra 16-bit-mode measurements that follow the f32 timed region (modes.f16, modes.bf16)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--in-flight', action='store_true',
+                    help='N > 1 only: also run the informational two-calls-in-flight leg of modes.* (at N = 1 it always runs); it issues the all-gathers '
+                         'alternately from two side streams, a pattern no multi-GPU run has exercised, so a scaling run leaves it out by default')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help=argparse.SUPPRESS)   # gloo: rehearsal of the N > 1 code path with ranks sharing one card (tests)
     ap.add_argument('--rng-mode', default='exact', choices=['exact', 'per_rank'])
     ap.add_argument('--host-init', action='store_true', help='generate the detinit weights with numpy on the host (same bits; keeps the ~8000 tiny init kernels out of a rocprofv3 counter pass)')
     ap.add_argument('--kernel-breakdown', action='store_true',
@@ -197,7 +202,7 @@ def main():
     # THIS process touches a GPU — the ranks are children (python -m torch.distributed.run), rank 0 prints the JSON line.
     from var_amd import launch
     if args.gpus > 1 and not launch.under_launcher():
-        sys.exit(launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+        sys.exit(launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus, need_gpus=args.backend == 'nccl'))
 
     import torch
     from var_amd import dist, hip
@@ -206,7 +211,7 @@ def main():
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world > 1 or ('RANK' in os.environ and 'MASTER_ADDR' in os.environ):      # under torchrun, a 1-rank launch too (exercises RCCL)
-        dist.initialize(backend='nccl')
+        dist.initialize(backend=args.backend)
     else:
         torch.cuda.set_device(0)
     rank = dist.get_rank()
@@ -232,10 +237,16 @@ def main():
     head = run_mode(var, args.dtype, args.steps, args.warmup, args, world, step, dist, hip, torch)
     # then, in the same process, the 16-bit throughput mode (what the reference's harness runs under torch.autocast(fp16)): its own warmup,
     # >= 10 timed steps, its own dominant kernel and roofline.  The headline value / dtype stay those of the parity mode.
-    others = {}
+    # N > 1: one stream, one all-gather per step as in the headline region (the two-stream leg only with --in-flight), and a failure here is
+    # reported inside `modes` instead of costing the headline line (every rank runs the same code, so a raise is a raise on all of them).
+    others, mode_errors = {}, {}
     if args.dtype == 'f32' and not args.no_modes:
         for dt16 in ('f16', 'bf16'):
-            others[dt16] = run_mode(var, dt16, max(10, args.steps), 2, args, world, step, dist, hip, torch, in_flight2=True)
+            try:
+                others[dt16] = run_mode(var, dt16, max(10, args.steps), 2, args, world, step, dist, hip, torch, in_flight2=(world == 1 or args.in_flight))
+            except Exception as e:          # noqa: BLE001
+                if world == 1: raise
+                mode_errors[dt16] = f'{type(e).__name__}: {e}'
 
     if rank == 0:
         precision = {'f32': 'fp32 parity mode', 'f16': 'fp16 GEMM / conv operands, activations and KV cache, fp32 accumulate and statistics',
@@ -271,6 +282,8 @@ def main():
                     'speedup_vs_one_call_at_a_time': round(v2 / ips2, 3),
                     'frac_of_mfma_peak_reference_flops': round(whole2['frac_of_mfma_peak_reference_flops'] * v2 / ips2, 4),
                     'how': 'the same calls issued alternately on two HIP streams of one process and model (per-stream workspaces); `value` above is one call at a time'}
+        for dt16, err in mode_errors.items():
+            out.setdefault('modes', {})[dt16] = {'error': err}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.depth, pns)
         print(json.dumps(out), flush=True)

@@ -121,7 +121,9 @@ int varhip_adaln_block_f32(float* x, float* x2, float* xn, float* q, float* att,
  *   idx = argmax_v softmax(x)[v] / noise[r][v]    (first max)  == torch.multinomial(p, 1, generator) with
  *              noise = empty_like(p).exponential_(1, generator)                      (helpers.py:19)
  * idx_out: int64 [B*l].  masked_out (optional, may be NULL): [B*l][V] the filtered logits (what the reference leaves in place).
- * Constraint: V % 256 == 0, V <= 8192, 0 <= top_k <= V. */
+ * Constraint: V % 256 == 0, V <= 8192, 0 <= top_k <= V; `logits` 16-byte aligned (rows are read 16 bytes per lane; V % 256 == 0 keeps
+ * every row aligned once the base is): VARHIP_EINVAL otherwise.  Any tensor start handed out by hipMalloc / torch's allocator qualifies;
+ * a view at an odd element offset does not — copy it first. */
 int varhip_cfg_sample_f32(const float* logits, const float* noise, int64_t* idx_out, float* masked_out,
                           int B, int l, int V, double t_cfg, int top_k, double top_p, varhip_stream_t stream);
 /* test hook: 1 = every top-p cut is decided by the sequential fp64 walk (the definition); 0 (default) = by a parallel prefix sum wherever

@@ -90,6 +90,28 @@ def test_bench_under_a_one_rank_torchrun_launch():
     assert len(lines) == 1 and json.loads(lines[0])['n_gpus'] == 1
 
 
+def test_bench_two_ranks_on_one_card_through_the_launcher():
+    """bench.py's own world > 1 branches executed as a whole before the driver's 8-GPU run does: `bench.py --gpus 2` outside torchrun starts two ranks
+    through var_amd/launch.py; with the rehearsal backend (gloo: RCCL refuses two ranks on one device) both share this card.  Closing barriers,
+    rank_stats, the all-gather of the decoded images and the modes.* legs (one stream, no two-stream collectives) all run; one JSON line comes out."""
+    cmd = [sys.executable, os.path.join(util.ROOT, 'bench.py'), '--gpus', '2', '--batch', '2', '--steps', '1', '--warmup', '0', '--no-cpu-baseline', '--backend', 'gloo']
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    out = subprocess.run(cmd, cwd=util.ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, f'expected exactly one JSON line, got {len(lines)}'
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['config']['global_batch'] == 4 and j['scaling'] == 'weak' and j['dtype'] == 'f32'
+    assert abs(j['value'] - 4 / (j['ms_per_step'] * 1e-3)) < 1e-2 * j['value']
+    r = j['ranks']
+    assert 0 < r['rank_ms_min'] <= r['rank_ms_max'] <= j['ms_per_step'] * 1.05
+    assert abs(r['allgather_mbytes'] - 4 * 3 * 256 * 256 * 4 / 1e6) < 0.06 and r['allgather_ms'] >= r['allgather_ms_min'] > 0
+    assert 'cpu_baseline' not in j
+    for dt16 in ('f16', 'bf16'):
+        m = j['modes'][dt16]
+        assert 'error' not in m and m['value'] > 0 and 'two_calls_in_flight' not in m and m['ranks']['rank_ms_min'] > 0
+
+
 _SHARD_CHILD = r'''
 import contextlib, io, os, sys, torch
 import torch.distributed as tdist

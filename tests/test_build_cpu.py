@@ -45,6 +45,21 @@ def test_checker_accepts_compiler_padded_reads_and_long_enough_gaps():
     assert cka.check_hazards(_asm(other)) == []
 
 
+def test_checker_follows_loop_back_edges():
+    """an MFMA at the bottom of a loop body, an inline-asm reader of its result at the top of the next iteration: only visible across the branch"""
+    loop = ('.LBB0_1:\n\t;;#ASMSTART\n\tv_max3_f32 v145, v145, v36, v37\n\t;;#ASMEND\n\tv_add_f32 v1, v1, v1\n\ts_nop 15\n\ts_nop 7\n'
+            + MFMA + '\n\ts_cbranch_scc1 .LBB0_1')
+    bad = cka.check_hazards(_asm(loop))
+    assert len(bad) == 1 and 'through a branch' in bad[0]
+    # the same loop with a compiler-generated first reader at the top is fine
+    ok = loop.replace('.LBB0_1:\n', '.LBB0_1:\n\ts_nop 15\n\ts_nop 1\n\tv_max_f32_e32 v9, v36, v37\n', 1)
+    assert cka.check_hazards(_asm(ok)) == []
+    # a forward branch over the padding into an asm reader
+    fwd = MFMA + '\n\ts_cbranch_vccz .LBB0_2\n\ts_nop 15\n\ts_nop 7\n.LBB0_2:\n\t;;#ASMSTART\n\tv_max3_f32 v145, v145, v36, v37\n\t;;#ASMEND'
+    bad = cka.check_hazards(_asm(fwd))
+    assert len(bad) == 1
+
+
 def test_checker_scratch_rules():
     meta = ['k1:                 ; @k1', '.LBB0_1:       ; =>This Inner Loop Header: Depth=1', '\tscratch_load_dword v1, off, off', '\ts_endpgm',
             'k2:                 ; @k2', '.LBB1_0:', '\tscratch_store_dword off, v1, off', '.LBB1_1:       ; =>This Inner Loop Header: Depth=1', '\tv_add_f32 v1, v1, v1', '\ts_endpgm',

@@ -276,6 +276,69 @@ def test_demo_sample_calling_convention():
     assert l1.dtype == torch.float32 and torch.equal(l1, l2)
 
 
+def test_precision_auto_follows_the_callers_autocast():
+    """set_hip_precision('auto') (opt-in; the default stays 'f32'): the demo's calling convention (demo_sample.py:66-68) under fp16 / bf16 autocast
+    equals an explicit set_hip_precision('f16' / 'bf16') bit for bit, outside the context (or with enabled=False) it equals the f32 call; the
+    teacher-forced VAR.forward follows the same rule (reference basic_var.py:97 branches on the autocast dtype)."""
+    z, meta = util.load_case('t_pn12345')
+    vae, var = build_models(meta)
+    labels = torch.tensor((980, 980, 437, 437, 22, 22, 562, 562), device='cuda')
+    B = labels.numel()
+    kw = dict(B=B, label_B=labels, cfg=4, top_k=900, top_p=0.95, g_seed=0, more_smooth=False)
+    var.cond_drop_rate = 0.0
+    x = torch.randn(B, var.L - var.first_l, var.Cvae, device='cuda')
+    try:
+        want, want_tf = {}, {}
+        with torch.inference_mode():
+            for prec in ('f32', 'f16', 'bf16'):
+                var.set_hip_precision(prec)
+                want[prec] = var.autoregressive_infer_cfg(**kw).clone()
+                want_tf[prec] = var(labels, x).clone()
+            assert not torch.equal(want['f32'], want['f16']) and not torch.equal(want['f16'], want['bf16'])
+            var.set_hip_precision('auto')
+            for prec, dt in (('f16', torch.float16), ('bf16', torch.bfloat16), ('f16', torch.float16)):
+                with torch.autocast('cuda', enabled=True, dtype=dt, cache_enabled=True):
+                    got, got_tf = var.autoregressive_infer_cfg(**kw), var(labels, x)
+                assert var.engine().precision == prec
+                assert torch.equal(got, want[prec]) and torch.equal(got_tf, want_tf[prec]), f"'auto' under {dt} autocast differs from set_hip_precision('{prec}')"
+                got = var.autoregressive_infer_cfg(**kw)                         # outside the context: f32
+                assert var.engine().precision == 'f32' and torch.equal(got, want['f32'])
+            with torch.autocast('cuda', enabled=False, dtype=torch.float16):
+                assert torch.equal(var.autoregressive_infer_cfg(**kw), want['f32'])
+            # the default policy ignores the context (test_demo_sample_calling_convention); an explicit mode does too
+            var.set_hip_precision('bf16')
+            with torch.autocast('cuda', enabled=True, dtype=torch.float16):
+                assert torch.equal(var.autoregressive_infer_cfg(**kw), want['bf16'])
+    finally:
+        var.set_hip_precision('f32')
+    with pytest.raises(ValueError):
+        var.set_hip_precision('fp8')
+
+
+def test_first_call_on_a_side_stream_without_warmup():
+    """Derived weight copies (16-bit casts, packed ada_lin, phase-packed conv kernels) are built by whichever call comes first, on ITS stream; a
+    call issued at once on another stream has to wait for those kernels (an event recorded behind them), not read half-written copies: no warm-up,
+    no synchronize between the two calls, results equal to the same calls issued serially afterwards."""
+    z, meta = util.load_case('d16_pn123')
+    for prec in ('f32', 'f16'):
+        _MODELS.clear()                                       # a model no call has touched yet: nothing derived exists
+        vae, var = build_models(meta)
+        var.rng = torch.Generator(device='cuda')
+        var.set_hip_precision(prec)
+        B = 4
+        labels = ((torch.arange(B) * 91) % 1000).cuda()
+        sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+        torch.cuda.synchronize()
+        with torch.inference_mode():
+            with torch.cuda.stream(sa): a = var.autoregressive_infer_cfg(B, labels, g_seed=5, cfg=1.5, top_k=900, top_p=0.96)
+            with torch.cuda.stream(sb): b = var.autoregressive_infer_cfg(B, labels, g_seed=6, cfg=1.5, top_k=900, top_p=0.96)
+            torch.cuda.synchronize()
+            a2 = var.autoregressive_infer_cfg(B, labels, g_seed=5, cfg=1.5, top_k=900, top_p=0.96)
+            b2 = var.autoregressive_infer_cfg(B, labels, g_seed=6, cfg=1.5, top_k=900, top_p=0.96)
+        assert torch.equal(a, a2) and torch.equal(b, b2), f'{prec}: a first call on a side stream read weights that were still being built'
+        var.set_hip_precision('f32')
+
+
 def test_public_api_and_properties():
     """VAR.autoregressive_infer_cfg with the device generator: determinism, output contract, and batch-slice invariance
     under injected noise (images are independent: SURVEY.md §8e), on the d16 (1,2,3) model."""

@@ -21,6 +21,8 @@ on `hipcc -S --cuda-device-only` output; tests/test_build_cpu.py runs it too).
                tolerance test caught).  An MFMA is settled once a compiler-generated (non-asm, non-MFMA) instruction has read or written
                one of its destination registers (the compiler put the wait states in front of that instruction, and instructions issue
                in order), or once 20 wait states' worth of instructions have issued behind it (`s_nop N` counts N + 1, anything else 1).
+               Control flow: the listing is walked linearly, and at every branch taken with MFMAs still unsettled the branch target is
+               walked as well with those MFMAs pending (loop back-edges included), one level deep.
 """
 import re
 import sys
@@ -41,19 +43,23 @@ def regs_of(text):
     return out
 
 
-def check_hazards(lines, fname='<asm>'):
-    """-> list of violation strings"""
-    bad = []
-    pending = []            # [dest regs (set), wait states issued since, line number, text] of unsettled MFMAs, oldest first
+def _scan(lines, start, pending, fname, bad, labels, follow):
+    """walk the listing from line index `start`; pending = unsettled MFMAs [dest regs, wait states since, line, text], oldest first.
+    follow=True (the linear pass over the file): at every branch with MFMAs still pending the branch TARGET is scanned too (follow=False,
+    until they are settled), so an MFMA at the bottom of a loop body followed by an inline-asm reader at the top of the next iteration — the
+    shape of the round-2 attention bug, across the back-edge — is seen.  A target scan ends when nothing is pending or the kernel ends."""
     in_asm = False
-    for ln, raw in enumerate(lines, 1):
+    seen = set()
+    for i in range(start, len(lines)):
+        ln, raw = i + 1, lines[i]
         s = raw.strip()
         if s.startswith(';;#ASMSTART'):
             in_asm = True; continue
         if s.startswith(';;#ASMEND'):
             in_asm = False; continue
         if not s or s.startswith((';', '.', '//')) or s.endswith(':'):
-            if s.startswith('.amdhsa_kernel') or s.startswith('.end_amdhsa_kernel'):
+            if s.startswith('.amdhsa_kernel') or s.startswith('.end_amdhsa_kernel') or _FUNC.match(raw):
+                if not follow: return
                 pending = []
             continue
         code = s.split(';')[0].strip()
@@ -61,6 +67,7 @@ def check_hazards(lines, fname='<asm>'):
             continue
         mnem = code.split()[0]
         if mnem == 's_endpgm':
+            if not follow: return
             pending = []; continue
         states = 1
         if mnem == 's_nop':
@@ -69,12 +76,13 @@ def check_hazards(lines, fname='<asm>'):
         is_mfma = mnem.startswith(('v_mfma', 'v_smfmac'))
         touched = regs_of(code[len(mnem):]) if mnem[0] in 'vdgbfs' else set()
         if pending and touched:
-            hit = [i for i, p in enumerate(pending) if p[0] & touched]
+            hit = [i2 for i2, p in enumerate(pending) if p[0] & touched]
             if hit:
                 if in_asm:
                     p = pending[hit[-1]]
-                    bad.append(f'{fname}:{ln}: inline-asm `{code}` touches the result of the MFMA at line {p[2]} (`{p[3]}`) only {p[1]} wait '
-                               f'state(s) behind it and before any compiler-generated reader')
+                    msg = (f'{fname}:{ln}: inline-asm `{code}` touches the result of the MFMA at line {p[2]} (`{p[3]}`) only {p[1]} wait '
+                           f'state(s) behind it and before any compiler-generated reader' + ('' if follow else ' (reached through a branch)'))
+                    if msg not in bad: bad.append(msg)
                 elif not is_mfma:
                     pending = pending[hit[-1] + 1:]          # the compiler padded this read: that MFMA and every older one have completed
         for p in pending:
@@ -85,6 +93,22 @@ def check_hazards(lines, fname='<asm>'):
             dest = regs_of(ops[0]) if ops else set()
             if dest:
                 pending.append([dest, 0, ln, code])
+        if not follow and not pending:
+            return
+        if mnem.startswith(('s_cbranch', 's_branch')) and pending:
+            tgt = code.split()[-1]
+            if follow and tgt in labels and (tgt, tuple(p[2] for p in pending)) not in seen:
+                seen.add((tgt, tuple(p[2] for p in pending)))
+                _scan(lines, labels[tgt], [[set(p[0]), p[1], p[2], p[3]] for p in pending], fname, bad, labels, False)
+            if not follow and mnem == 's_branch':
+                return                                       # (an unconditional jump inside a target scan: one level of following only)
+
+
+def check_hazards(lines, fname='<asm>'):
+    """-> list of violation strings"""
+    bad = []
+    labels = {m.group(1): i + 1 for i, raw in enumerate(lines) for m in [re.match(r'^(\.L[\w$]+):', raw.strip())] if m}
+    _scan(lines, 0, [], fname, bad, labels, True)
     return bad
 
 

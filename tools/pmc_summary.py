@@ -14,25 +14,69 @@ import sys
 from collections import defaultdict
 
 
+_FILT = next((f for f in ('/opt/rocm/lib/llvm/bin/llvm-cxxfilt', '/usr/bin/c++filt') if os.path.exists(f)), None)
+_DEMANGLED = {}
+
+
+def demangle(name: str) -> str:
+    """rocprofv3 prints some symbols mangled (_ZN6vh_f1612k_gn16_apply...): run them through llvm-cxxfilt once each"""
+    if not name.startswith('_Z') or _FILT is None:
+        return name
+    if name not in _DEMANGLED:
+        import subprocess
+        d = subprocess.run([_FILT, name], capture_output=True, text=True).stdout.strip() or name
+        _DEMANGLED[name] = d if not d.startswith('_Z') else _nested_name(name)
+    return _DEMANGLED[name]
+
+
+def _nested_name(name: str) -> str:
+    """fallback for symbols the installed c++filt cannot read (_Float16 / __bf16 parameter types, `DF16_` / `DF16b`): the nested name
+    `_ZN<len><id><len><id>...E` alone, which is all this script needs (non-template kernels only are printed mangled)"""
+    m = re.match(r'_ZN((?:\d+[A-Za-z_]\w*?)+)E', name)
+    if not m:
+        return name
+    parts, rest = [], m.group(1)
+    while rest:
+        n = re.match(r'\d+', rest)
+        if not n: return name
+        k = int(n.group(0)); parts.append(rest[n.end():n.end() + k]); rest = rest[n.end() + k:]
+    return '::'.join(parts) + '()'
+
+
 def short(name: str) -> str:
+    """'void vh_f16::k_gemm16<8, 4, 2, 4>(vh_f16::Params)' -> 'k_gemm16<8,4,2,4>': no return type, no argument list, no namespace (the 16-bit
+    kernels live in vh_f16:: / vh_bf16::, one flavour per profiled run; the namespace is kept beside the entry)"""
+    name = demangle(name.strip())
     name = re.sub(r'^void ', '', name)
     name = re.sub(r'\(.*$', '', name)
-    return name.replace(', ', ',')
+    head, lt, rest = name.partition('<')
+    head = head.split('::')[-1]
+    rest = re.sub(r'\b\w+::', '', rest)
+    return (head + lt + rest).replace(', ', ',')
+
+
+def namespace(name: str) -> str:
+    name = re.sub(r'^void ', '', demangle(name.strip()))
+    head = name.partition('<')[0].partition('(')[0]
+    return '::'.join(head.split('::')[:-1])
 
 
 def main():
     out, srcs = sys.argv[1], sys.argv[2:]
     acc = defaultdict(lambda: defaultdict(list))
+    spaces = {}
     for s in srcs:
         files = [s] if os.path.isfile(s) else glob.glob(os.path.join(s, '**', '*counter_collection.csv'), recursive=True)
         for f in files:
             for row in csv.DictReader(open(f)):
                 acc[short(row['Kernel_Name'])][row['Counter_Name']].append(float(row['Counter_Value']))
+                spaces.setdefault(short(row['Kernel_Name']), namespace(row['Kernel_Name']))
     kernels = {}
     for k, cs in acc.items():
         if not (k.startswith('k_') or k.startswith('void k_')):
             continue
         e = {'launches': max(len(v) for v in cs.values())}
+        if spaces.get(k): e['namespace'] = spaces[k]
         for c, v in cs.items():
             e[c + '_avg'] = round(sum(v) / len(v), 3)
         if 'FETCH_SIZE' in cs and 'WRITE_SIZE' in cs:

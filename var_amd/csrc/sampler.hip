@@ -169,9 +169,13 @@ __global__ void __launch_bounds__(256) k_cfg_sample(const float* __restrict__ lo
         bool cut_done = false;
         if (!split && thr > 1e-30f && cnt >= 2 && !force_walk) {
             const double mid = 0.5 * ((double)thr + (double)__uint_as_float(__float_as_uint(thr) + 1u));
+            // how close to mid a running sum may come before the walk has to decide: 1e-9 relative covers the reordering of the additions
+            // (n * 2^-53 relative), cnt * 2^-61 absolute covers the truncation of cnt probabilities to the 2^-62 grid — the larger of the two
+            // (for thr = 1 - top_p below ~4e-6, i.e. top_p within a few 1e-6 of one, the absolute term is the wider)
+            const double band = fmax(1e-9 * mid, (double)cnt * 4.336808689942018e-19);
             // The mass per byte value is summed in 2^-62 fixed point: integer LDS atomics do not mind the contention that the survivors'
             // clustered leading bytes put on a few addresses (fp64 atomics on one address serialise badly), the sums are exact in that grid and
-            // the same in every run; rounding a probability to the grid moves a sum by <= n * 2^-62 absolute — far inside the 1e-9 band below.
+            // the same in every run; rounding a probability to the grid moves a sum by <= n * 2^-62 absolute — inside `band` above.
             unsigned long long* const s_hs = reinterpret_cast<unsigned long long*>(&s_hist[0][0]);
             unsigned long long* const s_cu = reinterpret_cast<unsigned long long*>(s_cd);
             const double FX = 4611686018427387904.0, IFX = 1.0 / 4611686018427387904.0;       // 2^62
@@ -208,7 +212,7 @@ __global__ void __launch_bounds__(256) k_cfg_sample(const float* __restrict__ lo
                     if ((unsigned)(srt[e] >> 32) == prefix) { const int q = atomicAdd(&s_ntie, 1); if (q < 64) s_tie[q] = (unsigned)srt[e]; }
                 __syncthreads();
                 const int ntie = s_ntie;
-                if (ntie > 64 || fabs(C0 - mid) <= 1e-9 * mid) { if (tid == 0) s_fast = 0; }
+                if (ntie > 64 || fabs(C0 - mid) <= band) { if (tid == 0) s_fast = 0; }
                 __syncthreads();
                 unsigned rm = 0u;                                        // bit k: this thread's k-th entry is removed
                 if (s_fast) {
@@ -222,7 +226,7 @@ __global__ void __launch_bounds__(256) k_cfg_sample(const float* __restrict__ lo
                             for (int q = 0; q < ntie; ++q) rank += (s_tie[q] < idx) ? 1 : 0;
                             double c = C0;
                             for (int q = 0; q <= rank; ++q) c += pT;
-                            if (fabs(c - mid) <= 1e-9 * mid) atomicAnd(&s_fast, 0);
+                            if (fabs(c - mid) <= band) atomicAnd(&s_fast, 0);
                             else if (c < mid) rm |= 1u << k;
                         }
                     }

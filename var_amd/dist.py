@@ -28,6 +28,8 @@ def initialize(fork=False, backend='nccl', gpu_id_if_not_distibuted=0, timeout=3
         return
     rank, ngpu = int(os.environ['RANK']), torch.cuda.device_count()
     local = int(os.environ.get('LOCAL_RANK', rank % max(ngpu, 1)))
+    if backend == 'gloo':
+        local %= max(ngpu, 1)               # rehearsal of an N-rank job on fewer cards (ranks share a GPU and meet on the host); RCCL wants one GPU per rank
     torch.cuda.set_device(local)
     if not tdist.is_initialized():
         tdist.init_process_group(backend=backend, timeout=datetime.timedelta(seconds=timeout * 60))
@@ -66,9 +68,19 @@ def allgather(t: torch.Tensor, cat=True) -> Union[List[torch.Tensor], torch.Tens
         return t if cat else [t]
     if not t.is_cuda and tdist.get_backend() == 'nccl': t = t.cuda()       # RCCL moves device memory only
     t = t.contiguous()
-    out = torch.empty((_state['world'] * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    tdist.all_gather_into_tensor(out, t)
+    if t.is_cuda and tdist.get_backend() == 'gloo':                        # gloo moves host memory: stage through it (rehearsals only; the product backend is RCCL)
+        host = torch.empty((_state['world'] * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype)
+        tdist.all_gather_into_tensor(host, t.cpu())
+        out = host.to(t.device)
+    else:
+        out = torch.empty((_state['world'] * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        tdist.all_gather_into_tensor(out, t)
     return out if cat else list(out.chunk(_state['world'], dim=0))
+
+
+def collective_device(device):
+    """where small bookkeeping tensors of a collective must live: the GPU under RCCL, the host under gloo"""
+    return torch.device('cpu') if (_state['init'] and tdist.get_backend() == 'gloo') else device
 
 
 def broadcast(t: torch.Tensor, src_rank) -> None:

@@ -14,6 +14,7 @@ Differences from the reference's schedule (results unchanged):
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -84,9 +85,38 @@ class _VaeOps:
         self._sig = None
         self.w: Dict[str, torch.Tensor] = {}
         self._gn_part = None            # (tensor, partial sums, blocks per sample) left by the last conv for the GroupNorm after it
+        self._ready = None              # event recorded behind the kernels that built the packed copies (they run on whichever stream called first)
 
     def _signature(self):
         return _signature(self.vae.parameters())
+
+    def _built(self):
+        """packed copies were just (re)built on the current stream: calls arriving on OTHER streams wait for this event before they read them"""
+        self._ready = torch.cuda.Event()
+        self._ready.record()
+
+    def _wait_ready(self):
+        if self._ready is not None:
+            torch.cuda.current_stream().wait_event(self._ready)
+
+    def _retire(self):
+        """weights changed: before the old packed copies go back to the allocator, every stream that may still read them has to finish (a weight
+        change is rare — checkpoint load, EMA swap — so a device-wide wait is the simple safe form)"""
+        if self.w and torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    def _stats_from(self, x, B, HW, fn_full):
+        """(mean, rstd) per (sample, group) of a channels-last map: folded from the producing conv's per-block partial sums when it left them for
+        exactly this tensor, else by a statistics pass (`fn_full`) over x"""
+        Cc = x.shape[-1]
+        stats = torch.empty((B, 32, 2), dtype=torch.float32, device=x.device)
+        pend, self._gn_part = self._gn_part, None
+        if pend is not None and pend[0].data_ptr() == x.data_ptr() and pend[0].numel() == x.numel() and tuple(pend[1].shape) == (B, pend[2], Cc, 2):
+            hip.call('gn_stats_part_f32', pend[1], stats, B, pend[2], HW, Cc, 32, 1e-6)
+        else:
+            scratch = torch.empty(hip.gn_scratch_elems(B, HW, Cc, 32), dtype=torch.float64, device=x.device)
+            hip.call(fn_full, x, stats, scratch, B, HW, Cc, 32, 1e-6)
+        return stats
 
     def invalidate(self):
         """drop the packed weight copies: the next call re-reads the module's parameters"""
@@ -133,6 +163,7 @@ class DecoderEngine(_VaeOps):
         sig = self._signature()
         if sig == self._sig:
             return
+        self._retire()
         w = self._pack()
         for k in [k for k in w if k.endswith('.upsample.conv.weight')]:        # Upsample2x convs: pre-summed 2x2 phase weights
             cout, _, _, cin = w[k].shape
@@ -143,13 +174,16 @@ class DecoderEngine(_VaeOps):
         self.w16s = {}                       # {'f16' | 'bf16': 16-bit copies}: made by _ensure16() the first time such a decode runs on these weights
         self.nlev = 1 + max(int(k.split('.')[2]) for k in w if k.startswith('decoder.up.'))
         self._sig = sig
+        self._built()
 
     def _ensure16(self, prec):
         """16-bit copies of every conv kernel (3x3, phase, 1x1 shortcut, attention projections) next to the fp32 ones; biases and GroupNorm affine
         stay fp32.  Selects them (self.w16) and the flavour's entry-point suffix / dtype for the decode that follows."""
         if prec not in self.w16s:
+            self._wait_ready()
             self.w16s[prec] = {k: v.to(DT16[prec]).contiguous() for k, v in self.w.items()
                                if (k.endswith('.weight') or k.endswith('.phase')) and v.dim() >= 2 and '.norm' not in k}
+            self._built()
         self.w16, self.sfx, self.dt16 = self.w16s[prec], prec, DT16[prec]
 
     # -- building blocks ---------------------------------------------------------------------------------------------
@@ -172,32 +206,14 @@ class DecoderEngine(_VaeOps):
             hip.call('conv3x3_nhwc_f32', x, wt, self.w[key + '.bias'], resid, out, B, Hh, Ww, Cin, Cout, up2, out_mode)
         return out
 
-    def gn(self, x, key, B, HW, silu):
-        Cc = x.shape[-1]
-        stats = torch.empty((B, 32, 2), dtype=torch.float32, device=x.device)
-        pend = self._gn_part
-        self._gn_part = None
-        if pend is not None and pend[0].data_ptr() == x.data_ptr() and pend[0].numel() == x.numel() and tuple(pend[1].shape) == (B, pend[2], Cc, 2):
-            hip.call('gn_stats_part_f32', pend[1], stats, B, pend[2], HW, Cc, 32, 1e-6)
-        else:
-            scratch = torch.empty(hip.gn_scratch_elems(B, HW, Cc, 32), dtype=torch.float64, device=x.device)
-            hip.call('gn_stats_f32', x, stats, scratch, B, HW, Cc, 32, 1e-6)
-        out = torch.empty_like(x)
-        hip.call('gn_apply_f32', x, stats, self.w[key + '.weight'], self.w[key + '.bias'], out, B, HW, Cc, 32, int(silu))
-        return out
-
     def gn_stats(self, x, B, HW):
-        """(mean, rstd) per (sample, group): from the producing conv's partial sums when it left them, else a pass over x"""
-        Cc = x.shape[-1]
-        stats = torch.empty((B, 32, 2), dtype=torch.float32, device=x.device)
-        pend = self._gn_part
-        self._gn_part = None
-        if pend is not None and pend[0].data_ptr() == x.data_ptr() and pend[0].numel() == x.numel() and tuple(pend[1].shape) == (B, pend[2], Cc, 2):
-            hip.call('gn_stats_part_f32', pend[1], stats, B, pend[2], HW, Cc, 32, 1e-6)
-        else:
-            scratch = torch.empty(hip.gn_scratch_elems(B, HW, Cc, 32), dtype=torch.float64, device=x.device)
-            hip.call('gn_stats_f32', x, stats, scratch, B, HW, Cc, 32, 1e-6)
-        return stats
+        return self._stats_from(x, B, HW, 'gn_stats_f32')
+
+    def gn(self, x, key, B, HW, silu):
+        stats = self.gn_stats(x, B, HW)
+        out = torch.empty_like(x)
+        hip.call('gn_apply_f32', x, stats, self.w[key + '.weight'], self.w[key + '.bias'], out, B, HW, x.shape[-1], 32, int(silu))
+        return out
 
     def tail(self, h, B, Hh, Ww, denorm):
         """norm_out -> swish -> conv_out -> clamp (-> (x + 1) / 2) (basic_vae.py:224-226, vqvae.py:63, var.py:190): one pass over the map
@@ -290,17 +306,7 @@ class DecoderEngine(_VaeOps):
         return out
 
     def gn_stats16(self, x, B, HW):
-        """(mean, rstd) per (sample, group) of a 16-bit channels-last map: from the producing conv's partial sums when it left them, else a pass over x"""
-        Cc = x.shape[-1]
-        stats = torch.empty((B, 32, 2), dtype=torch.float32, device=x.device)
-        pend = self._gn_part
-        self._gn_part = None
-        if pend is not None and pend[0].data_ptr() == x.data_ptr() and pend[0].numel() == x.numel() and tuple(pend[1].shape) == (B, pend[2], Cc, 2):
-            hip.call('gn_stats_part_f32', pend[1], stats, B, pend[2], HW, Cc, 32, 1e-6)
-        else:
-            scratch = torch.empty(hip.gn_scratch_elems(B, HW, Cc, 32), dtype=torch.float64, device=x.device)
-            hip.call('gn_stats_' + self.sfx, x, stats, scratch, B, HW, Cc, 32, 1e-6)
-        return stats
+        return self._stats_from(x, B, HW, 'gn_stats_' + self.sfx)
 
     def gn16(self, x, key, B, HW, silu):
         stats = self.gn_stats16(x, B, HW)
@@ -405,7 +411,9 @@ class DecoderEngine(_VaeOps):
         prec = precision or self.precision
         if prec != 'f32':
             self._ensure16(prec)
+            self._wait_ready()
             return self._decode16(f_hat, denorm)
+        self._wait_ready()
         B, P = f_hat.shape[0], f_hat.shape[1]
         Hh = Ww = P
         h = self.conv3(f_hat, 'post_quant_conv', B, Hh, Ww)
@@ -545,9 +553,11 @@ class EncoderEngine(DecoderEngine):
         sig = self._signature()
         if sig == self._sig:
             return
+        self._retire()
         self.w = self._pack()
         self.nlev = 1 + max(int(k.split('.')[2]) for k in self.w if k.startswith('encoder.down.'))
         self._sig = sig
+        self._built()
 
     def conv_s2(self, x, key, B, Hh, Ww):
         wt = self.w[key + '.weight']
@@ -560,6 +570,7 @@ class EncoderEngine(DecoderEngine):
     def encode(self, img: torch.Tensor) -> torch.Tensor:
         """img (B,3,H,W) fp32 in [-1,1] -> f (B, H/16, W/16, Cvae) channels-last == quant_conv(encoder(img))"""
         self.refresh()
+        self._wait_ready()
         B, Ci, Hh, Ww = img.shape
         cin_pad = self.w['encoder.conv_in.weight'].shape[3]
         x = torch.empty((B, Hh, Ww, cin_pad), dtype=torch.float32, device=img.device)
@@ -581,16 +592,26 @@ class EncoderEngine(DecoderEngine):
 
 
 
+AUTOCAST_PRECISION = {torch.float16: 'f16', torch.bfloat16: 'bf16'}
+
+
 class SamplingEngine:
-    MAX_WORKSPACES = 4          # per-stream buffer sets kept alive (workspace())
-    """The AR loop of VAR.autoregressive_infer_cfg on HIP kernels.  One engine per VAR module; not re-entrant."""
+    """The AR loop of VAR.autoregressive_infer_cfg on HIP kernels.  One engine per VAR module; calls on different HIP streams may be in flight
+    together (per-stream workspaces), the host side is not thread-safe."""
+
+    MAX_WORKSPACES = 6          # buffer sets kept alive per engine (workspace(): one per (batch size, stream, precision) in use)
 
     def __init__(self, var):
         self.var = var
         self._sig = None
-        self._ws: Dict[tuple, dict] = {}            # (batch size, HIP stream) -> buffers of a call
+        self.w: dict = {}
+        self._ws: Dict[tuple, dict] = {}            # (batch size, HIP stream, precision) -> buffers of a call
+        self._ws_tf: Dict[tuple, dict] = {}         # the same for teacher_forced_logits
+        self._ready = None                          # event behind the kernels that built the derived weight copies (see _VaeOps._built)
+        self._labels_ok = None                      # identity of the last label tensor whose range was checked (one host sync saved per repeated call)
 
-        self.precision = 'f32'              # 'f16': the 16-bit throughput mode of the transformer (include/var_hip.h "f16"), explicitly selected
+        self.policy = 'auto' if os.environ.get('VARHIP_FOLLOW_AUTOCAST', '0') not in ('', '0') else 'f32'      # what set_precision() was given: 'f32' | 'f16' | 'bf16' | 'auto' (follow the caller's torch.autocast)
+        self.precision = 'f32'              # the arithmetic of the call in progress (the policy, resolved): 'f16' / 'bf16' = the 16-bit throughput mode (include/var_hip.h)
         self.dec = var.vae_proxy[0]._decoder_engine()       # the VQVAE's own engine: one packed copy of the decoder weights, one place to invalidate
         self.last_trace: Optional[dict] = None
 
@@ -600,9 +621,12 @@ class SamplingEngine:
         quant = var.vae_quant_proxy[0]
         sig = _signature(list(var.parameters()) + list(quant.parameters())) + (getattr(var.vae_proxy[0], '_hip_generation', 0),)
         if sig == self._sig:
+            self._ensure16()
             return
         if var.C != 64 * var.num_heads:
             raise hip.VarHipError(f'the HIP attention kernels are built for head_dim 64, got embed_dim {var.C} / {var.num_heads} heads')
+        if self.w and torch.cuda.is_available():
+            torch.cuda.synchronize()         # weights changed: other streams may still read the old derived copies that are dropped below (rare: checkpoint load, EMA swap)
         dev = var.pos_start.device
         w = {}
         g = lambda t, n: _chk(t.detach(), n)
@@ -627,20 +651,18 @@ class SamplingEngine:
                 smul=g(a.scale_mul_1H11, 'scale_mul').view(-1) if a.attn_l2_norm else None, l2=bool(a.attn_l2_norm), plain_scale=float(a.scale))
             if var.shared_aln:
                 d['gss'] = g(b.ada_gss, 'ada_gss').view(-1)
-            else:
-                d['ada_w'], d['ada_b'] = g(b.ada_lin[1].weight, 'ada_lin'), g(b.ada_lin[1].bias, 'ada_lin')
-            if self.precision != 'f32':      # 16-bit copies of the four GEMM weights (round-to-nearest-even, once per weight change)
-                for k in ('qkv_w', 'proj_w', 'fc1_w', 'fc2_w'):
-                    d[k + '16'] = d[k].to(DT16[self.precision]).contiguous()
             blocks.append(d)
         w['blocks'] = blocks
+        w['b16'], w['head_w16'] = {}, {}     # {'f16' | 'bf16': ...} 16-bit copies of the GEMM weights, made by _ensure16() when such a call first needs them
         if not var.shared_aln and var.depth * 6 * C * C * 4 < 3.5e9:          # (beyond: the weight rows would leave the GEMM's 32-bit request offsets)
             # all blocks' ada_lin projections as ONE GEMM per call (N = depth * 6C): sixteen launches of 192 workgroups each were bound by one
-            # workgroup's K loop (29 us each at d16); the packed copy (0.4 GB fp32 at d16) is rebuilt with the other copies when weights change
-            w['ada_w_all'] = torch.cat([d['ada_w'] for d in blocks], dim=0).contiguous()
-            w['ada_b_all'] = torch.cat([d['ada_b'] for d in blocks], dim=0).contiguous()
-        if self.precision != 'f32':
-            w['head_w16'] = w['head_w'].to(DT16[self.precision]).contiguous()
+            # workgroup's K loop (29 us each at d16).  The packed copy (0.4 GB fp32 at d16, 2.65 GB at d30; rebuilt when weights change) is the only
+            # copy the engine holds: the per-block path is not used beside it
+            w['ada_w_all'] = torch.cat([g(b.ada_lin[1].weight, 'ada_lin') for b in var.blocks], dim=0)
+            w['ada_b_all'] = torch.cat([g(b.ada_lin[1].bias, 'ada_lin') for b in var.blocks], dim=0)
+        elif not var.shared_aln:
+            for d, b in zip(blocks, var.blocks):
+                d['ada_w'], d['ada_b'] = g(b.ada_lin[1].weight, 'ada_lin'), g(b.ada_lin[1].bias, 'ada_lin')
         w['codebook'] = g(quant.embedding.weight, 'codebook')
         w['codebook_T'] = w['codebook'].t().contiguous()          # [Cvae][V]: "probabilities @ codebook" as an NT GEMM (more_smooth)
         phis = list(quant.quant_resi.phis())
@@ -653,6 +675,33 @@ class SamplingEngine:
                 w['taps'][pn] = (torch.from_numpy(ti).to(dev), torch.from_numpy(tw).to(dev))
         self.w = w
         self._sig = sig
+        self._labels_ok = None
+        self._built()
+        self._ensure16()
+
+    _built = _VaeOps._built
+    _wait_ready = _VaeOps._wait_ready
+
+    def _ensure16(self):
+        """16-bit copies of the four GEMM weights of every block and of the head (round-to-nearest-even, once per weight change and flavour), kept
+        per flavour so that calls alternating between precisions ('auto' inside and outside an autocast region) convert nothing twice"""
+        prec = self.precision
+        if prec == 'f32' or prec in self.w['b16']:
+            return
+        self._wait_ready()
+        dt = DT16[prec]
+        self.w['b16'][prec] = [{k + '16': d[k].to(dt).contiguous() for k in ('qkv_w', 'proj_w', 'fc1_w', 'fc2_w')} for d in self.w['blocks']]
+        self.w['head_w16'][prec] = self.w['head_w'].to(dt).contiguous()
+        self._built()
+
+    def resolve_precision(self) -> str:
+        """the arithmetic of the call that starts now: the policy itself, or under 'auto' what the caller's torch.autocast('cuda', dtype=...) asks for
+        (reference basic_var.py:97 branches on the dtype autocast hands it; demo_sample.py:66-68 is the caller)"""
+        if self.policy == 'auto':
+            self.precision = AUTOCAST_PRECISION.get(torch.get_autocast_dtype('cuda'), 'f32') if torch.is_autocast_enabled('cuda') else 'f32'
+        else:
+            self.precision = self.policy
+        return self.precision
 
     def set_precision(self, precision: str):
         """'f32' (default; the parity contract: token ids bit-identical to the CPU oracle), 'f16' or 'bf16': 16-bit weights / GEMM operands / KV
@@ -660,13 +709,13 @@ class SamplingEngine:
         (demo_sample.py:66-68), and the decoder call that ends the loop runs on fp16 activations / conv weights too (conv16.hip).  LayerNorm /
         GroupNorm statistics, AdaLN parameters, the residual stream, softmax, logits, sampler and quantizer stay fp32.  The VQVAE's own entry
         points (fhat_to_img, idxBl_to_img, ...) are NOT switched: the shared DecoderEngine is told the precision per call."""
-        if precision not in PRECISIONS:
-            raise ValueError(f"precision must be one of {PRECISIONS}")
-        if precision != self.precision:
+        if precision not in PRECISIONS + ('auto',):
+            raise ValueError(f"precision must be one of {PRECISIONS + ('auto',)}")
+        self.policy = precision
+        if precision != 'auto' and precision != self.precision:
             self.precision = precision
-            self._sig = None
-            self._ws = {}
-            if hasattr(self, '_ws_tf'): self._ws_tf = {}
+            self._ws = {k: v for k, v in self._ws.items() if k[2] == precision}          # an explicit switch releases the other modes' buffers (6-11 GB each at d16 / B=64)
+            self._ws_tf = {k: v for k, v in self._ws_tf.items() if k[2] == precision}
 
     def invalidate(self):
         """forget the packed weight copies of the sampling loop and of the decoder (call after editing parameters through `.data`)"""
@@ -679,7 +728,7 @@ class SamplingEngine:
         DIFFERENT streams may be in flight together — each owns its buffers, everything else a call allocates comes from torch's
         stream-ordered allocator — and a call's latency-bound small scales then run beside another call's decoder"""
         sid = int(torch.cuda.current_stream().cuda_stream)
-        ws = self._ws.get((B, sid))
+        ws = self._ws.get((B, sid, self.precision))
         dev = self.var.pos_start.device
         if ws is not None and ws['dev'] == dev:
             return ws
@@ -696,11 +745,30 @@ class SamplingEngine:
                   kc=[torch.zeros(2 * B, H, L, 64, dtype=act, device=dev) for _ in range(var.depth)],
                   vc=[torch.zeros(2 * B, H, L, 64, dtype=act, device=dev) for _ in range(var.depth)],
                   f_hat=e(B, P, P, Cv), up=e(B, P, P, Cv), pooled=e(B * lmax, Cv))
-        self._ws = {k: v for k, v in self._ws.items() if k[1] != sid}          # one batch size resident at a time (per stream)
-        while len(self._ws) >= self.MAX_WORKSPACES:                             # ... and a bounded number of streams (oldest first: a d16 / B=64 set is 6-11 GB;
-            self._ws.pop(next(iter(self._ws)))                                  # its memory returns to the stream it was allocated on, so work still queued there is safe)
-        self._ws[(B, sid)] = ws
+        self._ws = self._evict(self._ws, sid)
+        self._ws[(B, sid, self.precision)] = ws
         return ws
+
+    def _evict(self, cache: dict, sid: int) -> dict:
+        """make room for a new buffer set: one batch size resident at a time per (stream, precision), and a bounded number of sets (oldest first: a
+        d16 / B=64 set is 6-11 GB; its memory returns to the stream it was allocated on, so work still queued there is safe)"""
+        cache = {k: v for k, v in cache.items() if (k[1], k[2]) != (sid, self.precision)}
+        while len(cache) >= self.MAX_WORKSPACES:
+            cache.pop(next(iter(cache)))
+        return cache
+
+    def _check_labels(self, label_B: torch.Tensor):
+        """labels index class_emb: out-of-range ones must not reach the kernel.  One device-side reduction and ONE host sync (a sync drains the
+        stream, so back-to-back calls would otherwise never overlap their host side with the previous call's kernels); a tensor that was checked
+        before and has not been written since (same storage, same version counter) is not checked again."""
+        ident = (label_B.data_ptr(), _ver(label_B), label_B.numel(), label_B.device)
+        if ident == self._labels_ok and ident[1] >= 0:
+            return
+        lo, hi = torch.aminmax(label_B)
+        lo, hi = torch.stack((lo, hi)).tolist()
+        if lo < 0 or hi > self.var.num_classes:
+            raise ValueError(f'labels must lie in [0, {self.var.num_classes}]')
+        self._labels_ok = ident
 
     def gemm(self, A, W, bias, out, M, epi=EPI_NONE, resid=None, gamma=None, ldg=0, rpg=1):
         N, K = W.shape
@@ -715,9 +783,11 @@ class SamplingEngine:
             V, D = cb.shape
             idx = torch.empty(V, n, dtype=torch.int32, device=cb.device)
             dist = torch.empty(V, n, dtype=torch.float32, device=cb.device)
+            self._wait_ready()
             hip.call('neighbor_table_f32', cb, V, D, n, idx, dist)
             tabs.clear()                                        # one n resident at a time
             tabs[n] = (idx, dist)
+            self._built()
         return tabs[n]
 
     def block(self, blk, ws, bi, x, x2, rows, l, cur):
@@ -725,9 +795,10 @@ class SamplingEngine:
         var = self.var
         C = var.C
         if self.precision != 'f32':
+            b16 = self.w['b16'][self.precision][bi]
             hip.call('adaln_block_' + self.precision, x, x2, ws['xn'], ws['q'], ws['att'], ws['hid'], ws['ada_view'][bi][0], ws['ada_view'][bi][1],
-                     blk['qkv_w16'], blk['qkv_b'], blk['smul'], blk['plain_scale'], int(blk['l2']), blk['proj_w16'], blk['proj_b'],
-                     blk['fc1_w16'], blk['fc1_b'], blk['fc2_w16'], blk['fc2_b'], ws['kc'][bi], ws['vc'][bi],
+                     b16['qkv_w16'], blk['qkv_b'], blk['smul'], blk['plain_scale'], int(blk['l2']), b16['proj_w16'], blk['proj_b'],
+                     b16['fc1_w16'], blk['fc1_b'], b16['fc2_w16'], blk['fc2_b'], ws['kc'][bi], ws['vc'][bi],
                      rows, l, C, var.num_heads, blk['fc1_w'].shape[0], cur, var.L, var.norm_eps)
             return
         hip.call('adaln_block_f32', x, x2, ws['xn'], ws['q'], ws['att'], ws['hid'], ws['ada_view'][bi][0], ws['ada_view'][bi][1],
@@ -741,7 +812,7 @@ class SamplingEngine:
         C, V = var.C, var.V
         if self.precision != 'f32':
             hip.call(f'ln_modulate_{self.precision}out', x, hn, 2 * C, hn[:, C:], 2 * C, xn, M, C, l, var.norm_eps)
-            hip.call('gemm_nt_' + self.precision, xn, C, w['head_w16'], C, w['head_b'], logits, V, 0, M, V, C, EPI_NONE, None, 0, 0, None, 0, 1, 1, 0, 0, 0)
+            hip.call('gemm_nt_' + self.precision, xn, C, w['head_w16'][self.precision], C, w['head_b'], logits, V, 0, M, V, C, EPI_NONE, None, 0, 0, None, 0, 1, 1, 0, 0, 0)
         else:
             hip.call('ln_modulate_f32', x, hn, 2 * C, hn[:, C:], 2 * C, xn, M, C, l, var.norm_eps)
             self.gemm(xn, w['head_w'], w['head_b'], logits, M)
@@ -768,15 +839,16 @@ class SamplingEngine:
         accumulated log-likelihoods are left in self.last_smooth.
         force_idx/trace are test hooks (teacher forcing; keep per-scale logits/tokens/f_hat)."""
         var = self.var
+        self.resolve_precision()
         self.refresh()
+        self._wait_ready()
         w, ws = self.w, self.workspace(B)
         dev = ws['dev']
         C, H, V, Cv, S = var.C, var.num_heads, var.V, var.Cvae, len(var.patch_nums)
         P, B2 = var.patch_nums[-1], 2 * B
         if label_B.dtype != torch.int64 or label_B.numel() != B:
             raise ValueError('label_B must be an int64 tensor of B labels')
-        if int(label_B.min()) < 0 or int(label_B.max()) > var.num_classes:
-            raise ValueError(f'labels must lie in [0, {var.num_classes}]')
+        self._check_labels(label_B)
         label_B = label_B.to(dev).contiguous()
         tr = dict(logits=[], idx=[], f_hat=[], pooled=[]) if trace else None
         gt = keep_u8 = skip = masked = None
@@ -923,17 +995,18 @@ class SamplingEngine:
         mask `attn_bias_for_masking` allows (SURVEY.md §4 identity (i): identical to 3e-8 in the reference itself).
         No CFG doubling: B rows.  label_B may contain num_classes (dropped condition)."""
         var = self.var
+        self.resolve_precision()
         self.refresh()
+        self._wait_ready()
         w = self.w
         R = int(label_B.numel())                               # rows: one per image, no CFG pair
         dev = var.pos_start.device
         C, H, V, Cv, L = var.C, var.num_heads, var.V, var.Cvae, var.L
-        if int(label_B.min()) < 0 or int(label_B.max()) > var.num_classes:
-            raise ValueError(f'labels must lie in [0, {var.num_classes}]')
+        self._check_labels(label_B)
         lmax = max(p * p for p in var.patch_nums)
         hid = var.blocks[0].ffn.fc1.weight.shape[0]
         sid = int(torch.cuda.current_stream().cuda_stream)
-        ws = self._ws_tf.get((R, sid)) if hasattr(self, '_ws_tf') else None
+        ws = self._ws_tf.get((R, sid, self.precision))
         if ws is None or ws['dev'] != dev:
             e = lambda *s, dt=torch.float32: torch.empty(*s, dtype=dt, device=dev)
             act = DT16.get(self.precision, torch.float32)
@@ -944,8 +1017,8 @@ class SamplingEngine:
                       shared=e(R, 6 * C) if var.shared_aln else None,
                       kc=[torch.zeros(R, H, L, 64, dtype=act, device=dev) for _ in range(var.depth)],
                       vc=[torch.zeros(R, H, L, 64, dtype=act, device=dev) for _ in range(var.depth)])
-            self._ws_tf = {k: v for k, v in getattr(self, '_ws_tf', {}).items() if k[1] != sid}
-            self._ws_tf[(R, sid)] = ws
+            self._ws_tf = self._evict(self._ws_tf, sid)
+            self._ws_tf[(R, sid, self.precision)] = ws
         lab = label_B.to(dev).long().contiguous()
         hip.call('lvl_pos_f32', w['lvl_embed'], w['lvl_1L'], w['pos_1LC'], ws['lvl_pos'], L, C)
         hip.call('first_map_f32', w['class_emb'], lab, var.num_classes, w['pos_start'], ws['lvl_pos'], ws['cond'], ws['x'], R, C, var.first_l)

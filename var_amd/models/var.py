@@ -83,10 +83,13 @@ class VAR(nn.Module):
         return self._engine
 
     def set_hip_precision(self, precision: str = 'f32'):
-        """'f32' (default: tokens bit-identical to the CPU oracle, pixels within 1e-3 of the reference) or 'f16': fp16 weights / GEMM
+        """'f32' (default: tokens bit-identical to the CPU oracle, pixels within 1e-3 of the reference), 'f16' / 'bf16': 16-bit weights / GEMM
         operands / KV cache with fp32 accumulation — the arithmetic the reference's harness requests through
-        torch.autocast('cuda', dtype=torch.float16) (demo_sample.py:66-68), here selected explicitly (an enclosing autocast context does
-        not change the result of either mode)."""
+        torch.autocast('cuda', dtype=torch.float16) (demo_sample.py:66-68) — selected explicitly (an enclosing autocast context does not
+        change the result of any of the three), or 'auto': every call follows the caller's autocast state the way the reference does
+        (basic_var.py:97 branches on the dtype autocast hands it): inside torch.autocast('cuda', dtype=float16 | bfloat16) the call runs the
+        matching 16-bit mode, outside it (or with enabled=False) f32.  With 'auto' demo_sample.py runs its fp16 path unchanged.
+        The environment variable VARHIP_FOLLOW_AUTOCAST=1 makes 'auto' the initial policy of every new engine (default: 'f32')."""
         self.engine().set_precision(precision)
         return self
 

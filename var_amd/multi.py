@@ -75,7 +75,7 @@ def rank_stats(dt: float, dt_own: float, gather_ms: float, steps: int, gathered_
     rank_ms_max; ranks that arrive early wait inside the all-gather, so allgather_ms max - min is the arrival skew)."""
     import torch.distributed as tdist
     world = dist.get_world_size()
-    t = torch.tensor([dt, dt_own, gather_ms], device=device, dtype=torch.float64)
+    t = torch.tensor([dt, dt_own, gather_ms], device=dist.collective_device(device), dtype=torch.float64)
     allt = [torch.empty_like(t) for _ in range(world)]
     tdist.all_gather(allt, t)
     rows = [[float(v) for v in x.cpu()] for x in allt]
