@@ -60,6 +60,20 @@ def test_checker_follows_loop_back_edges():
     assert len(bad) == 1
 
 
+def test_checker_inplace_asm_mfma_chain():
+    """`v_mfma d, a, b, d` from inline asm (the accumulator pinned to one tuple, elem16.h): reading the previous MFMA's result as src C of the SAME tuple
+    is the accumulate chain, not a hazard; an asm MFMA that takes a fresh result as its A / B operand, or as a different tuple, still is"""
+    a = '\t;;#ASMSTART\n\tv_mfma_f32_16x16x32_f16 v[8:11], v[0:3], v[4:7], v[8:11]\n\t;;#ASMEND\n'
+    assert cka.check_hazards(_asm(a + a + a)) == []
+    bad = cka.check_hazards(_asm(a + '\t;;#ASMSTART\n\tv_mfma_f32_16x16x32_f16 v[12:15], v[8:11], v[4:7], v[12:15]\n\t;;#ASMEND'))
+    assert len(bad) == 1
+    bad = cka.check_hazards(_asm(a + '\t;;#ASMSTART\n\tv_mfma_f32_16x16x32_f16 v[12:15], v[0:3], v[4:7], v[8:11]\n\t;;#ASMEND'))
+    assert len(bad) == 1
+    # and a compiler-generated reader right behind an asm MFMA gets no padding from the compiler: it has to come >= 20 wait states later on its own
+    # (this checker cannot see that: the first non-asm toucher settles an MFMA by definition) — documented limit; VH16_MFMA_16x16x32_INPLACE's users keep a
+    # barrier and a waitcnt between the last MFMA and the epilogue
+
+
 def test_checker_scratch_rules():
     meta = ['k1:                 ; @k1', '.LBB0_1:       ; =>This Inner Loop Header: Depth=1', '\tscratch_load_dword v1, off, off', '\ts_endpgm',
             'k2:                 ; @k2', '.LBB1_0:', '\tscratch_store_dword off, v1, off', '.LBB1_1:       ; =>This Inner Loop Header: Depth=1', '\tv_add_f32 v1, v1, v1', '\ts_endpgm',

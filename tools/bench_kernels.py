@@ -29,7 +29,7 @@ def timeit(fn, iters):
 def gemm_shapes():
     B2 = 128
     out = []
-    for l in (256, 169, 100, 64, 36, 16, 4, 1):
+    for l in (256, 169, 100, 64, 36, 25, 16, 9, 4, 1):
         M = B2 * l
         out += [(f'qkv  l={l}', M, 3072, 1024, 0), (f'proj l={l}', M, 1024, 1024, 2), (f'fc1  l={l}', M, 4096, 1024, 1), (f'fc2  l={l}', M, 1024, 4096, 2)]
     out.append(('square 4096', 4096, 4096, 4096, 0))

@@ -77,6 +77,14 @@ def _scan(lines, start, pending, fname, bad, labels, follow):
         touched = regs_of(code[len(mnem):]) if mnem[0] in 'vdgbfs' else set()
         if pending and touched:
             hit = [i2 for i2, p in enumerate(pending) if p[0] & touched]
+            if hit and in_asm and is_mfma:
+                # an inline-asm MFMA that accumulates in place (`v_mfma d, a, b, d`, VH16_MFMA_16x16x32_INPLACE): its read of an older MFMA's result is
+                # the src C of the same register tuple — the accumulate chain, which the hardware interlocks (no software wait states for dst == src C
+                # of an identical tuple).  Only that exact overlap is exempt: an A / B operand or a partial overlap is still a violation.
+                ops_ = [o.strip() for o in code[len(mnem):].split(',')]
+                if len(ops_) >= 4 and ops_[0] == ops_[3]:
+                    own = regs_of(ops_[0]); ab = regs_of(ops_[1]) | regs_of(ops_[2])
+                    hit = [i2 for i2 in hit if not (pending[i2][0] == own and not (pending[i2][0] & ab))]
             if hit:
                 if in_asm:
                     p = pending[hit[-1]]

@@ -147,7 +147,11 @@ __global__ void __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(W
 #pragma unroll
             for (int i = 0; i < TMW; ++i)
 #pragma unroll
-                for (int j = 0; j < TNW; ++j) acc[i][j] = VH16_MFMA_16x16x32(bn[j], am[i], acc[i][j]);
+                for (int j = 0; j < TNW; ++j) {
+                    // (>= 16 accumulators: pinned in place, elem16.h — an accumulator's next MFMA is a whole K tile behind; the small tiles keep the builtin)
+                    if constexpr (TMW * TNW >= 16) VH16_MFMA_16x16x32_INPLACE(bn[j], am[i], acc[i][j]);
+                    else acc[i][j] = VH16_MFMA_16x16x32(bn[j], am[i], acc[i][j]);
+                }
         }
     }
     __syncthreads();                                              // the stages are free: the GroupNorm partials below reuse them
@@ -305,11 +309,18 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
     const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + (int64_t)b * hw * p.Cin), 0, (int)((int64_t)hw * p.Cin * 2), 0x00020000);
     const int drow = lane >> 2, dchunk = (lane & 3) ^ (((lane >> 4) & 1) << 1);
 
-    const uint32_t boff = (uint32_t)(((int64_t)(n0 + wave * 32 + drow) * p.K + dchunk * 8) * 2);
+    // the lane's part of a weight request — row (lane >> 2) of the 16-row piece, 16-byte slot (lane & 3) ^ swizzle — is rebuilt from the lane id at
+    // every request (eight vector instructions, volatile: neither hoisted nor kept): as a loop-invariant register it was spilled, and the scratch
+    // reload in front of the request brought an `s_waitcnt vmcnt(0)` that drained the weight pipeline at every step
+    const char* const wrow = (const char*)p.w + (size_t)(n0 + wave * 32) * p.K * 2;
+    const uint32_t k2 = (uint32_t)p.K * 2u;
     auto dma_b = [&](int c, int tap, int st) {                    // weight tile of (chunk c, tap) -> stage st
+        uint32_t l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        const uint32_t voff = (l >> 2) * k2 + ((((l & 3u) ^ ((l >> 3) & 2u))) << 4);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            vh16c_dma_glob((const char*)p.w + (size_t)(tap * p.Cin + c * 32) * 2 + (size_t)i * 16 * p.K * 2, boff,
+            vh16c_dma_glob(wrow + (size_t)(tap * p.Cin + c * 32) * 2 + (size_t)i * 16 * p.K * 2, voff,
                            (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(sB + st * BST + (wave * 2 + i) * 1024));
     };
     // source offsets of the patch pieces (piece j, lane) -> LDS table, once: the tile's geometry costs a dozen VALU and a 64-bit temporary
@@ -321,11 +332,17 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
         atab[e] = bad ? 0x80000000u : (uint32_t)(((y * p.Wd + x) * p.Cin + ((l & 3) ^ (((l >> 4) & 1) << 1)) * 8) * 2);
     }
     __syncthreads();
-    const uint32_t* const atab_l = atab + ((b_wave ? 0 : wave - NBW) * 64 + lane);      // one address register; the piece index is an immediate offset
+    // the lane's table slot is rebuilt from the lane id at every use (two v_mbcnt + one shift-add; volatile, so that it is neither hoisted nor
+    // kept): as a loop-invariant register it was the value the allocator spilled, and a scratch reload in front of every patch request brings
+    // an `s_waitcnt vmcnt(0)` that drains the request pipeline
+    const uint32_t atab_w = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(atab + (b_wave ? 0 : wave - NBW) * 64);
     auto dma_a = [&](int c, int k) {                              // piece k of this wave's share of chunk c's patch
         const int j = (wave - NBW) + NAW * k;
         if (k >= KP || j >= NPIECE) return;                       // wave-uniform
-        vh16c_dma_buf(arsrc, atab_l[NAW * 64 * k], (uint32_t)(c * 64), (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(smc + (c & 1) * PATCH + j * 1024));
+        uint32_t l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        const uint32_t voff = *(const __attribute__((address_space(3))) uint32_t*)(uintptr_t)(atab_w + (uint32_t)(NAW * 64 * k) * 4u + l * 4u);
+        vh16c_dma_buf(arsrc, voff, (uint32_t)(c * 64), (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(smc + (c & 1) * PATCH + j * 1024));
     };
 
     f32x4 acc[TMW][TNW];
@@ -334,7 +351,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
 #pragma unroll
         for (int j = 0; j < TNW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int r16 = lane & 15, kq = lane >> 4;
-    int rb = (PW == 32 ? wm * 2 * P : wm * 4 * P) + r16;          // patch row of this lane's pixel of fragment 0 at tap (0, 0)
+    // byte offset (inside a patch buffer) of this lane's 16 bytes of fragment 0 at tap (0, 0), before the bank swizzle: row * 64 + kq * 16.  A tap /
+    // fragment adds a multiple of 64 (rows), so row bit 2 — what the swizzle looks at — is bit 8 of the sum: address = w ^ ((w >> 3) & 32)
+    uint32_t ub = (uint32_t)(((PW == 32 ? wm * 2 * P : wm * 4 * P) + r16) * ROWB + (kq << 4));
     const int bsl = (wn * TNW * 16 + r16) * ROWB + ((kq << 4) ^ (((r16 >> 2) & 1) << 5));
     const int nch = p.Cin / 32;
 
@@ -344,38 +363,53 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
         for (int k = 0; k < KP; ++k) dma_a(0, k);
     }
     for (int c = 0; c < nch; ++c) {
-        const char* const pa = smc + (c & 1) * PATCH;
-        asm volatile("" : "+v"(rb));                                          // keeps the 36 tap addresses from being hoisted out of the chunk loop (they would spill)
+        const uint32_t pa = (uint32_t)((c & 1) * PATCH);
+        asm volatile("" : "+v"(ub));                                          // keeps the 36 tap addresses from being hoisted out of the chunk loop (they would spill)
+        // "is there a next chunk" as a value the optimiser cannot see through: with the plain comparison it peels the last chunk into a second copy
+        // of the nine taps, and in that copy it renames accumulators between MFMAs (dst != src C) and spills them (43 registers of scratch).
+        // The weight waves' schedule is the same in every chunk, the last included: its steps 7 and 8 request the first two weight tiles of chunk 0
+        // again (2 of 47 tiles; they land in stages nobody reads any more and are waited for before the epilogue reuses the LDS), so every step
+        // waits with the same vmcnt(2).
+        int more = __builtin_amdgcn_readfirstlane((c + 1 < nch) ? 1 : 0);
+        asm volatile("" : "+s"(more));
+        const int cn = more ? c + 1 : 0;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const bool last = (c == nch - 1) && t == 8;
-            if (b_wave) { if (last) vh16c_waitcnt_barrier<0>(); else vh16c_waitcnt_barrier<2>(); }        // this step's weight tile (and whatever is older) has landed
+            if (b_wave) vh16c_waitcnt_barrier<2>();                                                       // this step's weight tile (and whatever is older) has landed
             else if (t == 0) vh16c_waitcnt_barrier<0>();                                                  // this wave's share of the patch has landed
             else asm volatile("s_barrier" ::: "memory");
             if (b_wave) {                                                                               // two steps ahead; stage (t + 2) % 3 was read last in the previous step
                 if (t < 7) dma_b(c, t + 2, (t + 2) % 3);
-                else if (c + 1 < nch) dma_b(c + 1, t - 7, (t + 2) % 3);
-            } else if (t < ASTEPS && c + 1 < nch) { dma_a(c + 1, 2 * t); dma_a(c + 1, 2 * t + 1); }      // the other patch buffer was read last in the previous chunk
+                else dma_b(cn, t - 7, (t + 2) % 3);
+            } else if (t < ASTEPS && more) { dma_a(c + 1, 2 * t); dma_a(c + 1, 2 * t + 1); }             // the other patch buffer was read last in the previous chunk
             const int ky = t / 3, kx = t - ky * 3;
             const char* const sb = sB + (t % 3) * BST + bsl;
-            // rolling fragments: all of the weight tile's, two of the pixels' at a time (28 instead of 36 registers: the budget is 128)
-            h8 bn[TNW], am[2];
-            auto lda = [&](int i) { const int R = rb + (PW == 32 ? (i >> 1) * P + (i & 1) * 16 : i * P) + ky * P + kx;
-                                    return *(const h8*)(pa + R * ROWB + ((kq << 4) ^ (((R >> 2) & 1) << 5))); };
+            // rolling fragments: all four of the pixels', two of the weight tile's at a time (24 registers; all of the weights' + two of the pixels'
+            // were 28, and at 128 registers with 80 accumulators those four decide whether the allocator spills inside this loop)
+            h8 am[TMW], bq[2];
+            // (volatile add: rows of different (fragment, tap) pairs coincide — fragment 2 at ky is fragment 0 at ky + 1 — and the compiler kept
+            // such addresses in registers from one tap to the other: spills inside this loop.  Three vector instructions per read instead.)
+            auto lda = [&](int i) { const uint32_t off = pa + (uint32_t)(((PW == 32 ? (i >> 1) * P + (i & 1) * 16 : i * P) + ky * P + kx) * ROWB);
+                                    uint32_t w;
+                                    asm volatile("v_add_u32 %0, %1, %2" : "=v"(w) : "v"(ub), "s"(off));
+                                    return *(const h8*)(smc + (w ^ ((w >> 3) & 32u))); };
             am[0] = lda(0);
-#pragma unroll
-            for (int j = 0; j < TNW; ++j) bn[j] = *(const h8*)(sb + j * 16 * ROWB);
+            bq[0] = *(const h8*)(sb);
             am[1] = lda(1);
+            if (TNW > 1) bq[1] = *(const h8*)(sb + 16 * ROWB);
 #pragma unroll
-            for (int i = 0; i < TMW; ++i) {
+            for (int i = 2; i < TMW; ++i) am[i] = lda(i);
 #pragma unroll
-                for (int j = 0; j < TNW; ++j) acc[i][j] = VH16_MFMA_16x16x32(bn[j], am[i & 1], acc[i][j]);
+            for (int j = 0; j < TNW; ++j) {
+#pragma unroll
+                for (int i = 0; i < TMW; ++i) VH16_MFMA_16x16x32_INPLACE(bq[j & 1], am[i], acc[i][j]);
                 __builtin_amdgcn_sched_barrier(0);
-                if (i + 2 < TMW) am[i & 1] = lda(i + 2);
+                if (j + 2 < TNW) bq[j & 1] = *(const h8*)(sb + (j + 2) * 16 * ROWB);
             }
         }
     }
     __builtin_amdgcn_sched_barrier(0);                            // nothing of the epilogue moves up into the last taps (it spilled accumulators there)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (the weight waves' two surplus requests)
     __syncthreads();                                              // patches and stages are free: the epilogue reuses them
     asm volatile("" ::: "memory");
 
@@ -384,32 +418,28 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
     static_assert((size_t)8 * STG + (size_t)4 * BN * 2 * sizeof(double) <= (size_t)2 * PATCH + 3 * BST, "epilogue staging must fit");
     double* const red = reinterpret_cast<double*>(smc + 8 * STG);
     char* const stg = smc + wave * STG;
-    const int nw0 = n0 + wn * TNW * 16, col = lane % NC, pl = lane / NC, n = nw0 + col * 4;
+    // the epilogue's per-lane indices come from a lane id read HERE: derived from the `lane` of the prologue they were registers the allocator
+    // kept (spilled) across the whole K loop
+    int lane_e;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    const int r16e = lane_e & 15, kqe = lane_e >> 4, tid_e = wave * 64 + lane_e;
+    const int nw0 = n0 + wn * TNW * 16, col = lane_e % NC, pl = lane_e / NC, n = nw0 + col * 4;
     const bool lane_on = pl < PXI;
-    float b4[TNW][4];
-#pragma unroll
-    for (int j = 0; j < TNW; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) b4[j][e] = p.bias[nw0 + j * 16 + kq * 4 + e];
+    const f32x4 bcol = lane_on ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};      // added after the transposition (see k_conv16): 4 registers, not 4 * TNW
     float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < TMW; ++i) {
         const int trow = PW == 32 ? wm * 2 + (i >> 1) : wm * 4 + i, x0 = PW == 32 ? (i & 1) * 16 : 0;
         const int64_t mrow = ((int64_t)b * p.H + ty0 + trow) * p.Wd + tx0 + x0;
 #pragma unroll
-        for (int j = 0; j < TNW; ++j) {
-            f32x4 v = acc[i][j];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] + b4[j][e];
-            *(f32x4*)(stg + r16 * SROW + (j * 16 + kq * 4) * 4) = v;
-        }
+        for (int j = 0; j < TNW; ++j) *(f32x4*)(stg + r16e * SROW + (j * 16 + kqe * 4) * 4) = acc[i][j];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
             const int px = pl + PXI * k;
             if (!lane_on || px >= 16) continue;
             const int64_t m = mrow + px;
-            f32x4 v = *(const f32x4*)(stg + px * SROW + col * 16);
+            f32x4 v = *(const f32x4*)(stg + px * SROW + col * 16) + bcol;
             if (p.resid) { const h4 r4 = *(const h4*)(p.resid + m * p.N + n);
 #pragma unroll
                            for (int e = 0; e < 4; ++e) v[e] = (float)r4[e] + v[e]; }
@@ -427,16 +457,16 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
         for (int e = 0; e < 4; ++e) {
             float sm = gs[e], q = gq[e];
 #pragma unroll
-            for (int t = 1; t < PXI; ++t) { sm += __shfl(gs[e], lane + NC * t, 64); q += __shfl(gq[e], lane + NC * t, 64); }
+            for (int t = 1; t < PXI; ++t) { sm += __shfl(gs[e], lane_e + NC * t, 64); q += __shfl(gq[e], lane_e + NC * t, 64); }
             if (pl == 0) { const int nl = wn * TNW * 16 + col * 4 + e; red[(wm * BN + nl) * 2] = (double)sm; red[(wm * BN + nl) * 2 + 1] = (double)q; }
         }
         __syncthreads();
-        if (tid < BN) {                                             // two partials per tile (its upper and lower 128 pixels); any partition of a sample's pixels serves the statistics
+        if (tid_e < BN) {                                           // two partials per tile (its upper and lower 128 pixels); any partition of a sample's pixels serves the statistics
 #pragma unroll
             for (int hb = 0; hb < 2; ++hb) {
-                const double sm = red[(2 * hb * BN + tid) * 2] + red[((2 * hb + 1) * BN + tid) * 2];
-                const double q = red[(2 * hb * BN + tid) * 2 + 1] + red[((2 * hb + 1) * BN + tid) * 2 + 1];
-                double* o = p.gn_part + (((int64_t)b * (2 * tps) + 2 * trem + hb) * p.N + n0 + tid) * 2;
+                const double sm = red[(2 * hb * BN + tid_e) * 2] + red[((2 * hb + 1) * BN + tid_e) * 2];
+                const double q = red[(2 * hb * BN + tid_e) * 2 + 1] + red[((2 * hb + 1) * BN + tid_e) * 2 + 1];
+                double* o = p.gn_part + (((int64_t)b * (2 * tps) + 2 * trem + hb) * p.N + n0 + tid_e) * 2;
                 o[0] = sm; o[1] = q;
             }
         }
@@ -475,7 +505,7 @@ static int pick_conv16(const Conv16P& p, int nz) {
         && (int64_t)p.H * p.Wd * p.Cin * 2 < (1ll << 31)
         && (vh_g_conv16_force_wm == 8 || (int64_t)(p.M / 256) * (p.N / (p.N % 160 == 0 ? 160 : 128)) >= 256)) {
         const int64_t wgs = (int64_t)(p.M / 256) * (p.N / (p.N % 160 == 0 ? 160 : 128));
-        const bool w32 = (p.Wd % 32 == 0) && (p.H % 8 == 0), w16 = (p.Wd % 16 == 0) && (p.H % 16 == 0) && (vh_g_conv16_force_wm == 8 || wgs >= 512);
+        const bool w32 = (p.Wd % 32 == 0) && (p.H % 8 == 0), w16 = (p.Wd % 16 == 0) && (p.H % 16 == 0);      // (round 4: the 16x16-patch form no longer spills and beats the 256-pixel k_conv16 from one workgroup per CU on: 0.122 vs 0.137 ms at 640 -> 640, 16 x 16, B = 64)
         if (w32) return 1;
         if (w16) return 2;
     }
