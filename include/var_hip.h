@@ -314,6 +314,18 @@ int varhip_conv3x3_nhwc_f16(const void* in, const void* w, const float* bias, co
                             int B, int H, int W, int Cin, int Cout, int out_mode, varhip_stream_t stream);
 int varhip_upconv_phase_f16(const void* in, const void* w_phase, const float* bias, void* out, double* gn_part,
                             int B, int H, int W, int Cin, int Cout, varhip_stream_t stream);
+/* ResnetBlock's `conv(swish(norm(x)))` (basic_vae.py:57-60) in ONE launch: `in` is the RAW 16-bit map, table [B][2][Cin] fp32 its GroupNorm as one
+ * multiply-add per element (varhip_gn_scale_shift_f32 below: scale = rstd * gamma, shift = beta - mean * scale), silu != 0: swish.  The normalisation
+ * runs on the convolution's input patch in LDS, so the apply pass over the map (varhip_gn_apply_f16: one read + one write of every activation)
+ * disappears.  Bit-identical to varhip_gn_apply_f16 followed by varhip_conv3x3_nhwc_f16 (out_mode 0; bias, resid, gn_part as there).  Shapes:
+ * varhip_conv16_gn_fusable(B, H, W, Cin, Cout) != 0 (maps that tile into 8 x 32 or 16 x 16 patches with a workgroup for every CU, Cout % 128 == 0 or
+ * % 160 == 0, the table within the LDS budget: Cin <= 320 at 8 x 32 patches); VARHIP_EINVAL otherwise — the caller then runs the two launches. */
+int varhip_conv16_gn_fusable(int B, int H, int W, int Cin, int Cout);
+int varhip_gnconv3x3_nhwc_f16(const void* in, const float* table, int silu,
+                              const void* w, const float* bias, const void* resid, void* out, double* gn_part,
+                              int B, int H, int W, int Cin, int Cout, varhip_stream_t stream);
+/* table[b][0][c] = stats[b][g(c)].rstd * gamma[c], table[b][1][c] = beta[c] - stats[b][g(c)].mean * table[b][0][c]   (what varhip_gn_apply_* forms per channel) */
+int varhip_gn_scale_shift_f32(const float* stats, const float* gamma, const float* beta, float* table, int B, int C, int G, varhip_stream_t stream);
 /* testing / experiments: force the pixel tile of the following f16 convolutions (2: 128 pixels, 4 waves, two workgroups per CU;
  * 4: 256 pixels, 8 waves, two workgroups per CU; 8: the halo-patch kernel where the shape allows it; anything else: by size) */
 int varhip_conv16_force_tile(int wm);
@@ -356,6 +368,9 @@ int varhip_conv3x3_nhwc_bf16(const void* in, const void* w, const float* bias, c
                             int B, int H, int W, int Cin, int Cout, int out_mode, varhip_stream_t stream);
 int varhip_upconv_phase_bf16(const void* in, const void* w_phase, const float* bias, void* out, double* gn_part,
                             int B, int H, int W, int Cin, int Cout, varhip_stream_t stream);
+int varhip_gnconv3x3_nhwc_bf16(const void* in, const float* table, int silu,
+                               const void* w, const float* bias, const void* resid, void* out, double* gn_part,
+                               int B, int H, int W, int Cin, int Cout, varhip_stream_t stream);
 int varhip_conv16_force_tile(int wm);
 int varhip_gn_stats_bf16(const void* x, float* stats, double* scratch, int B, int HW, int C, int G, float eps, varhip_stream_t stream);
 int varhip_gn_apply_bf16(const void* x, const float* stats, const float* gamma, const float* beta, void* out,

@@ -409,6 +409,74 @@ def test_gn_silu_conv_out_fused_equals_two_launches(flav, B, H, W, Cin, Cout, om
         hip.call('gn_silu_conv_out_' + flav, x, stats, gamma, beta, w, bias, fused, B, H - 1, W, Cin, Cout, 32, omode)
 
 
+@pytest.mark.parametrize('flav', ['f16', 'bf16'])
+@pytest.mark.parametrize('B,H,W,Cin,Cout,res,silu', [(2, 8, 32, 32, 160, 0, 1), (1, 16, 64, 160, 160, 1, 1), (3, 24, 32, 64, 128, 1, 1), (2, 16, 16, 96, 160, 0, 1), (1, 32, 48, 320, 320, 1, 0),
+                                                     (2, 32, 32, 640, 640, 1, 1), (1, 64, 64, 320, 160, 0, 1), (64, 32, 32, 160, 160, 1, 1)])
+def test_gnconv16_fused_equals_apply_then_conv(flav, B, H, W, Cin, Cout, res, silu):
+    """ResnetBlock's conv(swish(norm(x))) (basic_vae.py:57-60) in one launch — GroupNorm + SiLU applied to the halo patch in LDS — against GroupNorm apply +
+    conv3x3 as two launches: identical bits in the map and in the GroupNorm partials it leaves (same arithmetic per element, same MFMA sequence); border
+    patches, residual, both patch shapes (8 x 32 and 16 x 16), both flavours"""
+    hip = _hip()
+    dt = torch.float16 if flav == 'f16' else torch.bfloat16
+    g = torch.Generator().manual_seed(H * 5 + W + Cin + Cout)
+    x = (torch.randn(B, H, W, Cin, generator=g) * 1.3 + 0.2).to(dt).cuda()
+    w = (torch.randn(Cout, 3, 3, Cin, generator=g) * (2.0 / (9 * Cin) ** 0.5)).to(dt).cuda()
+    bias = (torch.randn(Cout, generator=g) * 0.1).cuda()
+    resid = torch.randn(B, H, W, Cout, generator=g).to(dt).cuda() if res else None
+    gamma, beta = (torch.randn(Cin, generator=g) * 0.2 + 1.0).cuda(), (torch.randn(Cin, generator=g) * 0.2).cuda()
+    stats = torch.empty(B, 32, 2, dtype=torch.float32, device='cuda')
+    scratch = torch.empty(hip.gn_scratch_elems(B, H * W, Cin, 32), dtype=torch.float64, device='cuda')
+    hip.call('gn_stats_' + flav, x, stats, scratch, B, H * W, Cin, 32, 1e-6)
+    nblk = hip.conv_gn_blocks(H, W, Cout)
+    hip.lib().so.varhip_conv16_force_tile(8)                    # (small maps: the halo-patch kernel is otherwise chosen from one workgroup per CU on)
+    try:
+        fusable = hip.conv16_gn_fusable(B, H, W, Cin, Cout)
+        assert fusable == (not (Cin == 640 and W % 32 == 0 and H % 8 == 0)), 'the (scale, shift) table of 640 channels does not fit beside 8 x 32 patches'
+        xn = torch.empty_like(x)
+        hip.call('gn_apply_' + flav, x, stats, gamma, beta, xn, B, H * W, Cin, 32, silu)
+        table = torch.empty(B, 2, Cin, dtype=torch.float32, device='cuda')
+        hip.call('gn_scale_shift_f32', stats, gamma, beta, table, B, Cin, 32)
+        two = torch.empty(B, H, W, Cout, dtype=dt, device='cuda')
+        part2 = torch.zeros(B, nblk, Cout, 2, dtype=torch.float64, device='cuda') if nblk else None
+        hip.call('conv3x3_nhwc_' + flav, xn, w, bias, resid, two, part2, B, H, W, Cin, Cout, 0)
+        if not fusable:
+            with pytest.raises(Exception):
+                hip.call('gnconv3x3_nhwc_' + flav, x, table, silu, w, bias, resid, two, part2, B, H, W, Cin, Cout)
+            return
+        fused = torch.full((B, H, W, Cout), float('nan'), dtype=dt, device='cuda')
+        part1 = torch.zeros(B, nblk, Cout, 2, dtype=torch.float64, device='cuda') if nblk else None
+        hip.call('gnconv3x3_nhwc_' + flav, x, table, silu, w, bias, resid, fused, part1, B, H, W, Cin, Cout)
+    finally:
+        hip.lib().so.varhip_conv16_force_tile(0)
+    assert torch.equal(fused, two), f'fused differs from the two launches in {int((fused != two).sum())} of {fused.numel()} elements, max {float((fused.float() - two.float()).abs().max()):.3e}'
+    if nblk: assert torch.equal(part1, part2)
+    if B * H * W <= 70000:
+        ref = torch.nn.functional.conv2d(xn.double().cpu().permute(0, 3, 1, 2), w.double().cpu().permute(0, 3, 1, 2), bias.double().cpu(), padding=1)
+        if res: ref = ref + resid.double().cpu().permute(0, 3, 1, 2)
+        err = (fused.double().cpu().permute(0, 3, 1, 2) - ref).abs()
+        assert bool((err <= 1e-5 + ref.abs() * 2.0 ** (-10 if flav == 'f16' else -7) + 4e-6 * (9 * Cin) ** 0.5).all()), float(err.max())
+
+
+def test_decoder16_fused_groupnorm_equals_unfused():
+    """the 16-bit decoder with every GroupNorm + SiLU inside the conv that follows it (where the shape allows) against the same decoder with the apply
+    passes as launches of their own: the same image bit for bit (d16-size decoder, 256 x 256; B = 64 so that the 128^2 / 256^2 levels take the fused form)"""
+    z, meta = util.load_case('d16_full')
+    vae, var = _models(meta)
+    g = torch.Generator().manual_seed(5)
+    f_hat = (torch.randn(64, 32, 16, 16, generator=g) * 1.5).cuda()
+    eng = vae._decoder_engine()
+    for flav in ('f16', 'bf16'):
+        eng.set_precision(flav)
+        try:
+            with torch.inference_mode():
+                a = vae.fhat_to_img(f_hat).clone()
+                eng.fuse_gn = False
+                b = vae.fhat_to_img(f_hat).clone()
+        finally:
+            eng.set_precision('f32'); eng.fuse_gn = True
+        assert torch.equal(a, b), f'{flav}: max {float((a - b).abs().max()):.3e}'
+
+
 def test_decoder16_vs_fp32_decoder():
     """VQVAE.fhat_to_img in the 16-bit mode against the fp32 HIP decoder on the same f_hat (d16-size decoder, 256x256, B=2)"""
     z, meta = util.load_case('d16_full')

@@ -157,6 +157,15 @@ def run_conv16(iters):
             ms = timeit(fn, max(iters // 2, 2)); tf = 2.0 * B * H * W * Cout * (4 if up2 else 9) * Cin / ms / 1e9
             line += f'  [wm {t}] {ms:8.3f} ms {tf:7.1f} TF ({tf/2500*100:4.1f}%)'
         hip.lib().so.varhip_conv16_force_tile(0)
+        if not up2 and hip.conv16_gn_fusable(B, H, W, Cin, Cout):      # GroupNorm + SiLU inside the conv against apply pass + conv
+            gamma, beta = torch.randn(Cin, device=dev) * 0.2 + 1.0, torch.randn(Cin, device=dev) * 0.2
+            stats = torch.randn(B, 32, 2, device=dev).abs() + 0.5
+            xn = torch.empty_like(x)
+            t_apply = timeit(lambda: hip.call('gn_apply_f16', x, stats, gamma, beta, xn, B, H * W, Cin, 32, 1), max(iters // 2, 2))
+            t_conv = timeit(fn, max(iters // 2, 2))
+            table = torch.randn(B, 2, Cin, device=dev)
+            t_fused = timeit(lambda: hip.call('gnconv3x3_nhwc_f16', x, table, 1, w, b, r, out, part, B, H, W, Cin, Cout), max(iters // 2, 2))
+            line += f'   | GroupNorm apply {t_apply:6.3f} + conv {t_conv:6.3f} = {t_apply + t_conv:6.3f} ms, fused {t_fused:6.3f} ms'
         print(line, flush=True)
         del x, w, out, r, part
 

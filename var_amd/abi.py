@@ -61,6 +61,7 @@ SIGNATURES_F16 = {
     'adaln_block_f16':   [P, P, P, P, P, P, P, L, P, P, P, F, I, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, F],
     'conv3x3_nhwc_f16':  [P, P, P, P, P, P, I, I, I, I, I, I],
     'upconv_phase_f16':  [P, P, P, P, P, I, I, I, I, I],
+    'gnconv3x3_nhwc_f16': [P, P, I, P, P, P, P, P, I, I, I, I, I],
     'gn_stats_f16':      [P, P, P, I, I, I, I, F],
     'gn_apply_f16':      [P, P, P, P, P, I, I, I, I, I],
     'gn_silu_conv_out_f16': [P, P, P, P, P, P, P, I, I, I, I, I, I, I],
@@ -70,6 +71,7 @@ SIGNATURES_F16 = {
 
 # entry points of the HIP library that have no oracle twin of their own (they are pinned against other entry points bit for bit)
 SIGNATURES_HIP_ONLY = {
+    'gn_scale_shift_f32': [P, P, P, P, I, I, I],
     'gn_silu_conv_out_f32': [P, P, P, P, P, P, P, I, I, I, I, I, I, I],
 }
 
@@ -102,6 +104,11 @@ def bind(lib, prefix: str, with_stream: bool):
     cb.argtypes = [I, I, I, I]
     cb.restype = I
     fns['conv_gn_blocks'] = cb
+    if with_stream:
+        cf = getattr(lib, prefix + 'conv16_gn_fusable')
+        cf.argtypes = [I, I, I, I, I]
+        cf.restype = I
+        fns['conv16_gn_fusable'] = cf
     ver = getattr(lib, prefix + 'version')
     ver.argtypes = []
     ver.restype = C.c_char_p

@@ -23,6 +23,8 @@ struct Conv16P {
     int H, Wd, Cin, phase, out_mode;     // H, Wd: the map the M pixels live on; phase: Upsample2x phase form (grid.z = 4 phases)
     int64_t sW;                    // element stride between the phase weight sets
     int tilesM, tilesN;
+    // k_conv16h<.., GN = true>: the input is the RAW map; GroupNorm + SiLU are applied to the halo patch where it lies in LDS
+    const float* gn_table; int gn_silu;      // [B][2][Cin]: y = x * table[b][0][c] + table[b][1][c]
 };
 
 __device__ __forceinline__ void vh16c_dma_glob(const void* base, uint32_t voff, uint32_t lds) {
@@ -284,7 +286,13 @@ __global__ void __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(W
 // the other waves fetch the next chunk's patch during taps 0..ASTEPS-1 of the current one (two pieces per step, double-buffered) —
 // every wave's wait count is then a constant.  LDS rows of 64 bytes: slot c of row r holds chunk c ^ (((r >> 2) & 1) << 1), the one
 // family of swizzles under which ds_read_b128 of 16 CONSECUTIVE rows is conflict-free at ANY starting row (the taps shift it).
-template <int TNW, int PW>
+// GN = true (round 4; reference basic_vae.py:57-60 `conv(swish(norm(x)))`): the convolution takes the RAW map and the GroupNorm statistics and
+// applies y = SiLU(x * sc + sh) — k_gn16_apply's arithmetic operation for operation, one rounding to the 16-bit type — to the next chunk's halo patch
+// in place in LDS: the patch is waited for at tap 6 instead of tap 0 of its chunk, every thread then normalises three 16-byte units of it behind the
+// MFMAs of taps 6 and 7 (the (scale, shift) of all Cin channels sit in LDS; out-of-image pixels stay the zeros the bounds check wrote: the convolution
+// pads the NORMALISED map).  What it removes is the apply pass over the map (read + write of every activation in HBM) in front of every such conv.
+// The result is bit-identical to varhip_gn_apply_* followed by the plain convolution (tests).  Needs the registers the in-place accumulators freed.
+template <int TNW, int PW, bool GN>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) k_conv16h(Conv16P p) {
     constexpr int TMW = 4, BN = TNW * 32, ROWB = 64;
     constexpr int PH = 256 / PW, P = PW + 2, PROWS = (PH + 2) * P, NPIECE = (PROWS + 15) / 16, PATCH = NPIECE * 1024;
@@ -323,28 +331,68 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
             vh16c_dma_glob(wrow + (size_t)(tap * p.Cin + c * 32) * 2 + (size_t)i * 16 * p.K * 2, voff,
                            (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(sB + st * BST + (wave * 2 + i) * 1024));
     };
-    // source offsets of the patch pieces (piece j, lane) -> LDS table, once: the tile's geometry costs a dozen VALU and a 64-bit temporary
-    // per piece, and the loop below has no register to spare (a spill there would also put scratch traffic on the vmcnt the pipeline counts)
+    // source offset of every patch ROW (its pixel's channel 0 inside the sample, in bytes; bit 31: outside the image or past the patch — the
+    // descriptor's bounds check then writes zeros) -> LDS table, once: the tile's geometry costs a dozen VALU and a 64-bit temporary per row, and
+    // the loop below keeps no per-lane register for it.  A lane adds its 16-byte slot (bits 4-5; rows are multiples of 64 bytes apart).
     uint32_t* const atab = reinterpret_cast<uint32_t*>(smc + 2 * PATCH + 3 * BST);
-    for (int e = tid; e < NPIECE * 64; e += 512) {
-        const int l = e & 63, pr = (e >> 6) * 16 + (l >> 2), py = pr / P, px = pr - py * P, y = ty0 - 1 + py, x = tx0 - 1 + px;
+    for (int pr = tid; pr < NPIECE * 16; pr += 512) {
+        const int py = pr / P, px = pr - py * P, y = ty0 - 1 + py, x = tx0 - 1 + px;
         const bool bad = pr >= PROWS || (unsigned)y >= (unsigned)p.H || (unsigned)x >= (unsigned)p.Wd;
-        atab[e] = bad ? 0x80000000u : (uint32_t)(((y * p.Wd + x) * p.Cin + ((l & 3) ^ (((l >> 4) & 1) << 1)) * 8) * 2);
+        atab[pr] = bad ? 0x80000000u : (uint32_t)((y * p.Wd + x) * p.Cin * 2);
+    }
+    float* const scsh = reinterpret_cast<float*>(atab + NPIECE * 16);          // GN: [Cin] scale, then [Cin] shift of this sample
+    if constexpr (GN) {
+        // the sample's (scale, shift) table comes ready-made (varhip_gn_scale_shift_f32): built here from the statistics it was a chain of two
+        // dependent global loads + a division per channel at the head of every tile
+        const f32x4* const tab = reinterpret_cast<const f32x4*>(p.gn_table + (int64_t)b * 2 * p.Cin);
+        for (int q = tid; q < p.Cin / 2; q += 512) *(f32x4*)(scsh + 4 * q) = tab[q];
     }
     __syncthreads();
-    // the lane's table slot is rebuilt from the lane id at every use (two v_mbcnt + one shift-add; volatile, so that it is neither hoisted nor
+    // the lane's table slot is rebuilt from the lane id at every use (two v_mbcnt + a few shifts; volatile, so that it is neither hoisted nor
     // kept): as a loop-invariant register it was the value the allocator spilled, and a scratch reload in front of every patch request brings
     // an `s_waitcnt vmcnt(0)` that drains the request pipeline
-    const uint32_t atab_w = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(atab + (b_wave ? 0 : wave - NBW) * 64);
+    const uint32_t atab_s = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)atab;
     auto dma_a = [&](int c, int k) {                              // piece k of this wave's share of chunk c's patch
         const int j = (wave - NBW) + NAW * k;
         if (k >= KP || j >= NPIECE) return;                       // wave-uniform
         uint32_t l;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-        const uint32_t voff = *(const __attribute__((address_space(3))) uint32_t*)(uintptr_t)(atab_w + (uint32_t)(NAW * 64 * k) * 4u + l * 4u);
+        const uint32_t rowoff = *(const __attribute__((address_space(3))) uint32_t*)(uintptr_t)(atab_s + (uint32_t)(16 * j) * 4u + (l >> 2) * 4u);
+        const uint32_t voff = rowoff | (((l & 3u) ^ ((l >> 3) & 2u)) << 4);
         vh16c_dma_buf(arsrc, voff, (uint32_t)(c * 64), (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(smc + (c & 1) * PATCH + j * 1024));
     };
-
+    // GN: unit `base + lane` of chunk c's patch (a unit = 16 bytes = 8 channels of patch row unit >> 2), normalised in place
+    auto norm_patch = [&](int c, int base) {
+        uint32_t l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        const uint32_t u = (uint32_t)base + l, row = u >> 2;
+        if (u >= (uint32_t)(NPIECE * 64) || (atab[row] >> 31)) return;          // past the patch / outside the image: stays zero
+        const uint32_t cg = (u & 3u) ^ ((row >> 1) & 2u);                       // the 8-channel group this slot of this row holds (the read swizzle)
+        char* const ptr = smc + (c & 1) * PATCH + u * 16u;
+        const h8 v = *(const h8*)ptr;
+        const float* const sp = scsh + c * 32 + cg * 8;
+        const f32x4 s0 = *(const f32x4*)sp, s1 = *(const f32x4*)(sp + 4), h0 = *(const f32x4*)(sp + p.Cin), h1 = *(const f32x4*)(sp + p.Cin + 4);
+        float z[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float y = __builtin_fmaf((float)v[e], e < 4 ? s0[e & 3] : s1[e & 3], e < 4 ? h0[e & 3] : h1[e & 3]);
+            z[e] = p.gn_silu ? y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * y)) : y;
+        }
+        // (the product rounds to fp32 BEFORE the conversion, as in k_gn16_apply: hipcc otherwise merges the two into v_fma_mixlo_f16)
+        asm volatile("" : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]), "+v"(z[4]), "+v"(z[5]), "+v"(z[6]), "+v"(z[7]));
+        h8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (vh_e16)z[e];
+        *(h8*)ptr = o;
+    };
+    constexpr int NUNIT = (NPIECE * 64 + 511) / 512;              // units per thread and chunk (3)
+    // In the loop the next chunk's patch is waited for at tap 6 (tap 0 of its own chunk without GN) and every thread normalises its NUNIT units behind
+    // the MFMAs of taps 6 and 7.  What that costs is the units' vector instructions at full price (~200 per wave and chunk, two transcendentals per
+    // element: +12 % on a 160 -> 160 convolution at 256^2, +15 % at 320 channels) — a workgroup's step is a serial chain (barrier, requests, fragment
+    // reads, MFMA issue) that the matrix pipe only half fills, so nothing of a wave's own stream hides.  Measured alternatives, all slower
+    // (profiles/r04_gnconv_schedules.txt): the units cut into stages between the MFMA groups (+16 %), half of the waves per tap over taps 3 .. 8 with
+    // counted waits on the patch pieces (+16 %).  Against the apply pass it replaces (0.51 ms per 256^2 x 160 map at the HBM roof) the fusion keeps
+    // about half: 2.34 vs 2.61 ms per 160 -> 160 convolution at 256^2, 0.93 vs 1.08 at 320 -> 160 / 128^2, break-even at 64^2.
     f32x4 acc[TMW][TNW];
 #pragma unroll
     for (int i = 0; i < TMW; ++i)
@@ -362,6 +410,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
 #pragma unroll
         for (int k = 0; k < KP; ++k) dma_a(0, k);
     }
+    if constexpr (GN) {                                           // chunk 0's patch: landed, seen by everyone, normalised (the loop's first barrier publishes it)
+        if (b_wave) asm volatile("s_barrier" ::: "memory"); else vh16c_waitcnt_barrier<0>();
+#pragma unroll
+        for (int k = 0; k < NUNIT; ++k) norm_patch(0, k * 512 + wave * 64);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     for (int c = 0; c < nch; ++c) {
         const uint32_t pa = (uint32_t)((c & 1) * PATCH);
         asm volatile("" : "+v"(ub));                                          // keeps the 36 tap addresses from being hoisted out of the chunk loop (they would spill)
@@ -376,7 +430,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             if (b_wave) vh16c_waitcnt_barrier<2>();                                                       // this step's weight tile (and whatever is older) has landed
-            else if (t == 0) vh16c_waitcnt_barrier<0>();                                                  // this wave's share of the patch has landed
+            else if (t == (GN ? 9 - NUNIT : 0)) vh16c_waitcnt_barrier<0>();                                       // this wave's share of the (next) patch has landed
             else asm volatile("s_barrier" ::: "memory");
             if (b_wave) {                                                                               // two steps ahead; stage (t + 2) % 3 was read last in the previous step
                 if (t < 7) dma_b(c, t + 2, (t + 2) % 3);
@@ -405,6 +459,13 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
                 for (int i = 0; i < TMW; ++i) VH16_MFMA_16x16x32_INPLACE(bq[j & 1], am[i], acc[i][j]);
                 __builtin_amdgcn_sched_barrier(0);
                 if (j + 2 < TNW) bq[j & 1] = *(const h8*)(sb + (j + 2) * 16 * ROWB);
+            }
+            if constexpr (GN) {
+                if (t == 9 - NUNIT && more) {
+#pragma unroll
+                    for (int k = 0; k < NUNIT - 1; ++k) norm_patch(c + 1, k * 512 + wave * 64);
+                }
+                if (t == 10 - NUNIT && more) { norm_patch(c + 1, (NUNIT - 1) * 512 + wave * 64); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }   // drained before the barrier that opens the next chunk
             }
         }
     }
@@ -473,15 +534,21 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
     }
 }
 
+// LDS of one k_conv16h workgroup: two patch buffers, three weight stages, the row table (+ the GroupNorm (scale, shift) table); two workgroups per CU
 template <int TNW, int PW>
+static constexpr size_t conv16h_lds(int gn_cin) {
+    return (size_t)2 * ((((256 / PW) + 2) * (PW + 2) + 15) / 16) * 1024 + (size_t)3 * TNW * 32 * 64 + (size_t)((((256 / PW) + 2) * (PW + 2) + 15) / 16) * 64 + (size_t)gn_cin * 8;
+}
+template <int TNW, int PW, bool GN>
 static int launch_conv16h(Conv16P& p, hipStream_t s) {
-    constexpr int BN = TNW * 32, PH = 256 / PW, NPIECE = ((PH + 2) * (PW + 2) + 15) / 16;
-    constexpr size_t lds = (size_t)2 * NPIECE * 1024 + (size_t)3 * BN * 64 + (size_t)NPIECE * 256;
-    static_assert(lds <= 80 * 1024, "two workgroups per CU");
+    constexpr int BN = TNW * 32, PH = 256 / PW;
+    static_assert(conv16h_lds<TNW, PW>(0) <= 80 * 1024, "two workgroups per CU");
+    const size_t lds = conv16h_lds<TNW, PW>(GN ? p.Cin : 0);
+    if (lds > 80 * 1024) return VARHIP_EINVAL;
     p.tilesM = (p.M / (p.H * p.Wd)) * (p.H / PH) * (p.Wd / PW); p.tilesN = p.N / BN;
-    auto kfn = k_conv16h<TNW, PW>;
+    auto kfn = k_conv16h<TNW, PW, GN>;
     static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr_done = true; }
     hipLaunchKernelGGL(kfn, dim3(p.tilesM * p.tilesN), dim3(512), lds, s, p);
     return vh_launch_status();
 }
@@ -517,8 +584,13 @@ static int pick_conv16(const Conv16P& p, int nz) {
 static int conv16_family(const Conv16P& p, int nz) { return (pick_conv16(p, nz) == 1 && p.N % 160 == 0) ? VH_FAM_CONV16H : VH_FAM_CONV16_SMALL; }
 static int dispatch_conv16(Conv16P& p, int nz, hipStream_t s) {
     const int pick = pick_conv16(p, nz);
-    if (pick == 1) return p.N % 160 == 0 ? launch_conv16h<5, 32>(p, s) : launch_conv16h<4, 32>(p, s);
-    if (pick == 2) return p.N % 160 == 0 ? launch_conv16h<5, 16>(p, s) : launch_conv16h<4, 16>(p, s);
+    if (p.gn_table) {                                             // the GroupNorm-fused form exists in the halo-patch kernel only (callers ask varhip_conv16_gn_fusable first)
+        if (pick == 1) return p.N % 160 == 0 ? launch_conv16h<5, 32, true>(p, s) : launch_conv16h<4, 32, true>(p, s);
+        if (pick == 2) return p.N % 160 == 0 ? launch_conv16h<5, 16, true>(p, s) : launch_conv16h<4, 16, true>(p, s);
+        return VARHIP_EINVAL;
+    }
+    if (pick == 1) return p.N % 160 == 0 ? launch_conv16h<5, 32, false>(p, s) : launch_conv16h<4, 32, false>(p, s);
+    if (pick == 2) return p.N % 160 == 0 ? launch_conv16h<5, 16, false>(p, s) : launch_conv16h<4, 16, false>(p, s);
     const bool big = pick == 3;
     if (p.N % 160 == 0) return big ? launch_conv16<5, 3, 4, 2>(p, nz, s) : launch_conv16<5, 4, 2>(p, nz, s);
     if (p.N % 128 == 0) return big ? launch_conv16<4, 3, 4, 2>(p, nz, s) : launch_conv16<4, 4, 2>(p, nz, s);
@@ -547,6 +619,39 @@ extern "C" int VH16_FN(conv3x3_nhwc)(const void* in, const void* w, const float*
     Conv16P p{};
     p.in = (const vh_e16*)in; p.w = (const vh_e16*)w; p.bias = bias; p.out = out; p.resid = (const vh_e16*)resid; p.gn_part = gn_part;
     p.M = B * H * W; p.N = Cout; p.K = 9 * Cin; p.H = H; p.Wd = W; p.Cin = Cin; p.phase = 0; p.out_mode = out_mode; p.sW = 0;
+    const double npix = (double)B * H * W;
+    VhScope scope(conv16_family(p, 1), (hipStream_t)stream, 2.0 * npix * Cout * 9.0 * Cin,
+                  2.0 * (npix * Cin + npix * Cout * (resid ? 2.0 : 1.0) + 9.0 * Cin * Cout));
+    return dispatch_conv16(p, 1, (hipStream_t)stream);
+}
+
+// out = conv3x3(SiLU?(GroupNorm(in))) + bias (+ resid) in ONE launch: `in` is the RAW map, stats [B][G][2] = (mean, rstd) as varhip_gn_stats_* /
+// varhip_gn_stats_part_f32 leave them.  Bit-identical to varhip_gn_apply_* followed by varhip_conv3x3_nhwc_* (out_mode 0).  Only shapes the halo-patch
+// kernel takes (varhip_conv16_gn_fusable(...) != 0); anything else returns VARHIP_EINVAL and the caller runs the two launches.
+static int conv16_gn_fusable(int B, int H, int W, int Cin, int Cout) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (Cin & 31)) return 0;
+    Conv16P p{};
+    p.M = B * H * W; p.N = Cout; p.K = 9 * Cin; p.H = H; p.Wd = W; p.Cin = Cin;
+    const int pick = pick_conv16(p, 1);
+    if (pick != 1 && pick != 2) return 0;
+    const size_t lds = pick == 1 ? (Cout % 160 == 0 ? conv16h_lds<5, 32>(Cin) : conv16h_lds<4, 32>(Cin)) : (Cout % 160 == 0 ? conv16h_lds<5, 16>(Cin) : conv16h_lds<4, 16>(Cin));
+    return lds <= 80 * 1024 ? 1 : 0;
+}
+#ifndef VH_BF16
+extern "C" int varhip_conv16_gn_fusable(int B, int H, int W, int Cin, int Cout) { return conv16_gn_fusable(B, H, W, Cin, Cout); }
+#endif
+extern "C" int VH16_FN(gnconv3x3_nhwc)(const void* in, const float* table, int silu,
+                                         const void* w, const float* bias, const void* resid, void* out, double* gn_part,
+                                         int B, int H, int W, int Cin, int Cout, varhip_stream_t stream) {
+    int rc = conv16_checks(in, w, bias, out, B, H, W, Cin, Cout);
+    if (rc) return rc;
+    if (!table || ((uintptr_t)table & 15) || !conv16_gn_fusable(B, H, W, Cin, Cout)) return VARHIP_EINVAL;
+    if (gn_part && (!varhip_conv_gn_blocks(H, W, Cout, 0) || (Cout & 3))) return VARHIP_EINVAL;
+    if ((int64_t)Cout * 9 * Cin * 2 >= (1ll << 32)) return VARHIP_EINVAL;
+    Conv16P p{};
+    p.in = (const vh_e16*)in; p.w = (const vh_e16*)w; p.bias = bias; p.out = out; p.resid = (const vh_e16*)resid; p.gn_part = gn_part;
+    p.M = B * H * W; p.N = Cout; p.K = 9 * Cin; p.H = H; p.Wd = W; p.Cin = Cin; p.phase = 0; p.out_mode = 0; p.sW = 0;
+    p.gn_table = table; p.gn_silu = silu ? 1 : 0;
     const double npix = (double)B * H * W;
     VhScope scope(conv16_family(p, 1), (hipStream_t)stream, 2.0 * npix * Cout * 9.0 * Cin,
                   2.0 * (npix * Cin + npix * Cout * (resid ? 2.0 : 1.0) + 9.0 * Cin * Cout));

@@ -302,6 +302,26 @@ extern "C" int varhip_gn_stats_part_f32(const double* part, float* stats, int B,
     return vh_launch_status();
 }
 
+// GroupNorm as one multiply-add per element: table[b][0][c] = rstd * gamma[c], table[b][1][c] = beta[c] - mean * (rstd * gamma[c]) — the two numbers
+// k_gn_apply / k_gn16_apply form per channel (same operations, same order), for the convolution that applies the norm to its own input patch
+// (varhip_gnconv3x3_nhwc_*, conv16.hip)
+__global__ void __launch_bounds__(256) k_gn_scale_shift(const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float* __restrict__ table, int B, int C, int G) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i - b * C;
+    const float* st = stats + ((int64_t)b * G + c / (C / G)) * 2;
+    const float sc = st[1] * gamma[c];
+    table[((int64_t)b * 2) * C + c] = sc;
+    table[((int64_t)b * 2 + 1) * C + c] = beta[c] - st[0] * sc;
+}
+extern "C" int varhip_gn_scale_shift_f32(const float* stats, const float* gamma, const float* beta, float* table, int B, int C, int G, varhip_stream_t stream) {
+    if (B <= 0 || C <= 0 || G <= 0 || (C % G) || !stats || !gamma || !beta || !table) return VARHIP_EINVAL;
+    VhScope sc(VH_FAM_GN, (hipStream_t)stream, 0, 8.0 * B * C);
+    hipLaunchKernelGGL(k_gn_scale_shift, dim3((B * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, gamma, beta, table, B, C, G);
+    return vh_launch_status();
+}
+
 // SiLU of the decoder's GroupNorm: hardware exp2 / rcp (about 1 ulp each) instead of include/var_math.h's reproducible forms.
 // The decoder is off the token path (pixels within 1e-3 of the reference, measured ~1e-6); this halves the kernel's VALU work.
 __device__ __forceinline__ float gn_fast_silu(float y) {

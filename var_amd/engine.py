@@ -328,17 +328,34 @@ class DecoderEngine(_VaeOps):
         h = self.gn16(h, 'decoder.norm_out', B, Hh * Ww, True)
         return self.conv3_16(h, 'decoder.conv_out', B, Hh, Ww, out_mode=1 if denorm else 2)
 
+    fuse_gn = os.environ.get('VARHIP_FUSE_GN', '1') != '0'      # False (tests, A/B runs): every GroupNorm + SiLU as its own pass in front of the conv (the same bits)
+
+    def gnconv3_16(self, x, nkey, ckey, B, Hh, Ww, resid=None):
+        """conv(swish(norm(x))) (basic_vae.py:57-60): one launch where the halo-patch conv can normalise its own input patch, else apply pass + conv"""
+        wt = self.w16[ckey + '.weight']
+        Cout, Cin = wt.shape[0], wt.shape[3]
+        if not (self.fuse_gn and hip.conv16_gn_fusable(B, Hh, Ww, Cin, Cout)):
+            return self.conv3_16(self.gn16(x, nkey, B, Hh * Ww, True), ckey, B, Hh, Ww, resid=resid, stats=True)
+        stats = self.gn_stats16(x, B, Hh * Ww)
+        out = torch.empty((B, Hh, Ww, Cout), dtype=self.dt16, device=x.device)
+        nblk = hip.conv_gn_blocks(Hh, Ww, Cout) if Cout % 4 == 0 else 0
+        part = self._part_buffer(B, nblk, Cout, x.device) if nblk else None
+        table = torch.empty((B, 2, Cin), dtype=torch.float32, device=x.device)
+        hip.call('gn_scale_shift_f32', stats, self.w[nkey + '.weight'], self.w[nkey + '.bias'], table, B, Cin, 32)
+        hip.call('gnconv3x3_nhwc_' + self.sfx, x, table, 1, wt, self.w[ckey + '.bias'], resid, out, part, B, Hh, Ww, Cin, Cout)
+        if nblk: self._gn_part = (out, part, nblk)
+        return out
+
     def resblock16(self, x, pre, B, Hh, Ww):
         HW = Hh * Ww
-        h = self.conv3_16(self.gn16(x, pre + '.norm1', B, HW, True), pre + '.conv1', B, Hh, Ww, stats=True)
-        hn = self.gn16(h, pre + '.norm2', B, HW, True)
+        h = self.gnconv3_16(x, pre + '.norm1', pre + '.conv1', B, Hh, Ww)
         sc = x
         if (pre + '.nin_shortcut.weight') in self.w16:              # 1x1 conv == fp16 GEMM over the pixels
             wt = self.w16[pre + '.nin_shortcut.weight']
             N, K = wt.shape
             sc = torch.empty((B, Hh, Ww, N), dtype=self.dt16, device=x.device)
             hip.call('gemm_nt_' + self.sfx, x, K, wt, K, self.w[pre + '.nin_shortcut.bias'], sc, N, 1, B * HW, N, K, EPI_NONE, None, 0, 0, None, 0, 1, 1, 0, 0, 0)
-        return self.conv3_16(hn, pre + '.conv2', B, Hh, Ww, resid=sc, stats=True)
+        return self.gnconv3_16(h, pre + '.norm2', pre + '.conv2', B, Hh, Ww, resid=sc)
 
     def attnblock16(self, x, pre, B, Hh, Ww):
         """AttnBlock (basic_vae.py:73-92) on fp16 activations: the five products (q/k projection, V^T projection, q.k^T, p.v, proj_out + residual)

@@ -75,6 +75,11 @@ def conv_gn_blocks(H, W, Cout, phase=False) -> int:
     return int(lib().fn['conv_gn_blocks'](H, W, Cout, 1 if phase else 0))
 
 
+def conv16_gn_fusable(B, H, W, Cin, Cout) -> bool:
+    """can the 16-bit conv apply the GroupNorm + SiLU in front of it to its own input patch (varhip_gnconv3x3_nhwc_*)?"""
+    return bool(lib().fn['conv16_gn_fusable'](B, H, W, Cin, Cout))
+
+
 # ---- timing table --------------------------------------------------------------------------------------------------
 NFAM = 15            # VARHIP_NFAM of include/var_hip.h
 
