@@ -49,10 +49,11 @@ PEAK_HBM_GBS = 8000.0
 FAMILY_PEAK = {'gemm': PEAK_F32_MFMA_TFLOPS, 'gemm_small': PEAK_F32_MFMA_TFLOPS, 'conv3x3': PEAK_F32_MFMA_TFLOPS, 'conv_small': PEAK_F32_MFMA_TFLOPS,
                'attn': PEAK_F32_MFMA_TFLOPS, 'gemm16': PEAK_F16_MFMA_TFLOPS, 'gemm16_small': PEAK_F16_MFMA_TFLOPS, 'conv16h': PEAK_F16_MFMA_TFLOPS,
                'conv16_small': PEAK_F16_MFMA_TFLOPS, 'attn16': PEAK_F16_MFMA_TFLOPS}
-# families that can dominate a step -> the kernel symbol behind them (gemm / conv3x3 / gemm16 (the persistent 256x256 kernel) / conv16h: exactly one symbol; the attention
-# families: one template, 1-4 waves per workgroup by l)
+# families that can dominate a step -> the kernel symbol behind them (gemm / conv3x3 / gemm16 (the persistent 256x256 kernel): exactly one symbol; conv16h: the halo-patch
+# kernel at 160 output channels, GroupNorm-fused (<5,32,true>: all but one launch of a decode) or plain (<5,32,false>); the attention families: one template, 1-4 waves per
+# workgroup by l)
 DOMINANT = {'f32': {'gemm': 'k_dma_gemm<4,4,false,2,false>', 'conv3x3': 'k_dma_gemm<4,5,true,2,false>', 'attn': 'k_attn_cached<NW>'},
-            'f16': {'gemm16': 'k_gemm16p', 'conv16h': 'k_conv16h<5,32>', 'attn16': 'k_attn16<NW>'}}
+            'f16': {'gemm16': 'k_gemm16p', 'conv16h': 'k_conv16h<5,32,true>', 'attn16': 'k_attn16<NW>'}}
 DOMINANT['bf16'] = DOMINANT['f16']          # the same kernels compiled with the bf16 MFMA opcodes (namespace vh_bf16 in the symbol)
 
 

@@ -31,16 +31,28 @@ def demangle(name: str) -> str:
 
 def _nested_name(name: str) -> str:
     """fallback for symbols the installed c++filt cannot read (_Float16 / __bf16 parameter types, `DF16_` / `DF16b`): the nested name
-    `_ZN<len><id><len><id>...E` alone, which is all this script needs (non-template kernels only are printed mangled)"""
-    m = re.match(r'_ZN((?:\d+[A-Za-z_]\w*?)+)E', name)
-    if not m:
+    `_ZN<len><id><len><id>...[I<integer literal arguments>E]E` alone, which is all this script needs — e.g. _ZN6vh_f168k_attn16ILi4EEEvPKDF16_... ->
+    vh_f16::k_attn16<4>()"""
+    if not name.startswith('_ZN'):
         return name
-    parts, rest = [], m.group(1)
-    while rest:
+    parts, rest = [], name[3:]
+    while rest and rest[0].isdigit():
         n = re.match(r'\d+', rest)
-        if not n: return name
         k = int(n.group(0)); parts.append(rest[n.end():n.end() + k]); rest = rest[n.end() + k:]
-    return '::'.join(parts) + '()'
+    if not parts:
+        return name
+    targs = ''
+    if rest.startswith('I'):                                   # template arguments: integer / bool literals only (L<type><value>E)
+        vals, rest2 = [], rest[1:]
+        while rest2.startswith('L'):
+            m = re.match(r'L([a-z])(n?\d+)E', rest2)
+            if not m: return name
+            v = m.group(2).replace('n', '-')
+            vals.append({'0': 'false', '1': 'true'}.get(v, v) if m.group(1) == 'b' else v)
+            rest2 = rest2[m.end():]
+        if not rest2.startswith('E'): return name
+        targs = '<' + ', '.join(vals) + '>'
+    return '::'.join(parts) + targs + '()'
 
 
 def short(name: str) -> str:
