@@ -10,6 +10,7 @@
 // 16-byte fragment.  The score accumulators of a lane (C layout: register e = key (e & 3) + 8 (e >> 2) + 4h) become the B operand of the
 // second product by pairwise conversion to fp16 (registers 8s .. 8s+7 = the fragment of step s); the V^T fragment of that step is stored
 // in LDS in the matching key order (cdna_hip_programming.md §3, "an accumulator tile as the next MFMA's operand").
+#include <type_traits>
 #include "common.h"
 #include "elem16.h"
 
@@ -100,10 +101,20 @@ __global__ void __launch_bounds__(NW * 64, NW) k_attn16(const vh_e16* __restrict
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int kxor = (r >> 1) & 7;
-    for (int kt = 0; kt < ntile; ++kt) {
-        const int buf = kt & 1;
+    // one key tile; the stage index is a compile-time constant (the loop below runs two tiles per trip): every LDS address of the tile is then a
+    // register + immediate instead of ~20 vector adds per tile, and the V^T fragments are requested at the top of the tile, a whole Q.K^T + softmax
+    // ahead of their use (16 registers; the reads used to sit right in front of the second product)
+    auto tile = [&](int kt, auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
         if (kt + 1 < ntile) { dma_k(kt + 1, buf ^ 1); dma_v(kt + 1, buf ^ 1); }
         if (t0 < l) {
+            // V^T fragments of step s: elements 0..3 = keys 16s + 4h + 0..3, elements 4..7 = keys 16s + 8 + 4h + 0..3 (the order of pf); [s][2 c32 + u]
+            vs4 va[2][4];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4)
+                    va[s][q4] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) vs4*)v_addr(buf, s, q4 & 1, q4 >> 1));
             f32x16 p;
             {
                 const char* kb = sK + buf * KST + r * 128;
@@ -150,19 +161,19 @@ __global__ void __launch_bounds__(NW * 64, NW) k_attn16(const vh_e16* __restrict
                 for (int j = 0; j < 8; ++j) pf[s][j] = (vh_e16)p[8 * s + j];
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                // V^T fragments of step s: elements 0..3 = keys 16s + 4h + 0..3, elements 4..7 = keys 16s + 8 + 4h + 0..3 (the order of pf)
-                const vs4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) vs4*)v_addr(buf, s, 0, 0));
-                const vs4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) vs4*)v_addr(buf, s, 1, 0));
-                const vs4 c0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) vs4*)v_addr(buf, s, 0, 1));
-                const vs4 c1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) vs4*)v_addr(buf, s, 1, 1));
-                const h8 v0 = __builtin_shufflevector(__builtin_bit_cast(h4, a0), __builtin_bit_cast(h4, a1), 0, 1, 2, 3, 4, 5, 6, 7);
-                const h8 v1 = __builtin_shufflevector(__builtin_bit_cast(h4, c0), __builtin_bit_cast(h4, c1), 0, 1, 2, 3, 4, 5, 6, 7);
+                const h8 v0 = __builtin_shufflevector(__builtin_bit_cast(h4, va[s][0]), __builtin_bit_cast(h4, va[s][1]), 0, 1, 2, 3, 4, 5, 6, 7);
+                const h8 v1 = __builtin_shufflevector(__builtin_bit_cast(h4, va[s][2]), __builtin_bit_cast(h4, va[s][3]), 0, 1, 2, 3, 4, 5, 6, 7);
                 o0 = VH16_MFMA_32x32x16(v0, pf[s], o0);      // channels r
                 o1 = VH16_MFMA_32x32x16(v1, pf[s], o1);      // channels r + 32
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+    };
+    {
+        int kt = 0;
+        for (; kt + 1 < ntile; kt += 2) { tile(kt, std::integral_constant<int, 0>{}); tile(kt + 1, std::integral_constant<int, 1>{}); }
+        if (kt < ntile) tile(kt, std::integral_constant<int, 0>{});
     }
     float inv;
     {
