@@ -40,8 +40,9 @@ def main():
     ap.add_argument('--top-p', type=float, default=0.95)
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--more-smooth', action='store_true')
-    ap.add_argument('--precision', default='f32', choices=['f32', 'f16', 'bf16'],
-                    help="f32: token ids bit-identical to the CPU oracle; f16: what the demo's torch.autocast(dtype=float16) asks for (demo_sample.py:66-68); bf16: the same with bfloat16")
+    ap.add_argument('--precision', default='f32', choices=['f32', 'f16', 'bf16', 'auto'],
+                    help="f32: token ids bit-identical to the CPU oracle; f16: what the demo's torch.autocast(dtype=float16) asks for (demo_sample.py:66-68); bf16: the same with bfloat16; "
+                         "auto: exactly the demo — the call sits inside torch.autocast('cuda', dtype=torch.float16) and the engine follows it")
     ap.add_argument('--vae-ckpt'); ap.add_argument('--var-ckpt')
     ap.add_argument('--out', default='sample.png')
     a = ap.parse_args()
@@ -64,7 +65,8 @@ def main():
     labels = torch.tensor(a.labels, device='cuda')
     var.set_hip_precision(a.precision)
     with torch.inference_mode():
-        img = var.autoregressive_infer_cfg(B=len(a.labels), label_B=labels, cfg=a.cfg, top_k=a.top_k, top_p=a.top_p, g_seed=a.seed, more_smooth=a.more_smooth)
+        with torch.autocast('cuda', enabled=a.precision == 'auto', dtype=torch.float16, cache_enabled=True):       # (demo_sample.py:66)
+            img = var.autoregressive_infer_cfg(B=len(a.labels), label_B=labels, cfg=a.cfg, top_k=a.top_k, top_p=a.top_p, g_seed=a.seed, more_smooth=a.more_smooth)
     grid = make_grid(img)
     try:
         from PIL import Image
