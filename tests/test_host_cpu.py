@@ -261,6 +261,35 @@ def test_sharded_sampling_two_ranks_gloo(mode, tmp_path):
         assert p.returncode == 0, f'rank {r} failed:\n{o}'
 
 
+def test_eight_rank_partition_reproduces_the_one_gpu_stream():
+    """BASELINE.json configs[2]'s partition at its real width (8 ranks, B = 512 -> 64 per rank), as far as one process can show it: every rank's shard of the
+    'exact' RNG mode (each rank draws the whole Exp(1) fill and keeps its rows), concatenated in rank order, is the single-rank result row for row; 'per_rank'
+    shards differ from it but are reproducible"""
+    import torch
+    from var_amd import multi
+
+    class FakeVar:
+        V = 32
+        lvl_1L = torch.zeros(1)
+        rng = torch.Generator()
+        patch_nums = (1, 2, 3, 4)
+
+    def fake_sample(B_local, labels, noise_fn):
+        acc = labels.float().view(B_local, 1).clone()
+        for si, pn in enumerate(FakeVar.patch_nums):
+            acc = acc + noise_fn(si, pn * pn).view(B_local, -1).sum(dim=1, keepdim=True) * (si + 1)
+        return acc
+
+    B, W = 512, 8
+    labels = (torch.arange(B) * 7) % 1000
+    whole = multi.sample_sharded(FakeVar, B, labels, g_seed=3, rng_mode='exact', sample_fn=fake_sample, rank=0, world=1)
+    parts = [multi.sample_sharded(FakeVar, B, labels, g_seed=3, rng_mode='exact', sample_fn=fake_sample, rank=r, world=W, gather=False) for r in range(W)]
+    assert all(p.shape[0] == B // W for p in parts) and torch.equal(torch.cat(parts), whole)
+    a = [multi.sample_sharded(FakeVar, B, labels, g_seed=3, rng_mode='per_rank', sample_fn=fake_sample, rank=r, world=W, gather=False) for r in range(W)]
+    b = [multi.sample_sharded(FakeVar, B, labels, g_seed=3, rng_mode='per_rank', sample_fn=fake_sample, rank=r, world=W, gather=False) for r in range(W)]
+    assert all(torch.equal(x, y) for x, y in zip(a, b)) and not torch.equal(torch.cat(a), whole)
+
+
 def test_shard_range_rejects_ragged_batches():
     from var_amd.multi import shard_range
     assert shard_range(512, 3, 8) == (192, 256)
